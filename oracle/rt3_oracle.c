@@ -1,0 +1,1105 @@
+/*
+ * rt3_oracle.c -- CPU ORACLE (test infrastructure, NOT the product).  See rt3_oracle.h.
+ *
+ * Every function cites the reference file:line (relative to /root/reference) it restates.  Functions marked
+ * [north_star] have no reference counterpart (the reference uses the Vulkan driver's BVH and has no NEE / sky /
+ * blue-noise code); they define the estimator the HIP product must reproduce.
+ *
+ * Arithmetic contract shared with the product (DESIGN.md "Arithmetic contract"): fp32 everywhere, no FMA
+ * contraction (build with -ffp-contract=off), +,-,*,/,sqrt correctly rounded, min/max as explicit ternaries,
+ * transcendental functions only through the polynomials defined here.  With that, product and oracle are
+ * expected to agree bit for bit; tests state the tolerance they actually need.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fno-fast-math -pthread).
+ */
+#include "rt3_oracle.h"
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------------ helpers */
+#define F_PI 3.14159265358979323846f
+#define F_TAU 6.28318530717958647692f       /* math.slang:3 */
+#define F_FRAC_1_PI 0.318309886183790671538f /* math.slang:4 */
+#define F_HALF_PI 1.57079632679489661923f
+
+static inline float fminx(float a, float b) { return a < b ? a : b; }
+static inline float fmaxx(float a, float b) { return a > b ? a : b; }
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline float dot3(const float a[3], const float b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static inline void cross3(const float a[3], const float b[3], float o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static inline void normalize3(float v[3]) {
+    float inv = 1.0f / sqrtf(dot3(v, v));
+    v[0] *= inv; v[1] *= inv; v[2] *= inv;
+}
+
+/* simple parallel-for over [0,n) in contiguous chunks */
+typedef void (*pf_body)(void *ctx, uint32_t begin, uint32_t end, int tid);
+typedef struct { pf_body fn; void *ctx; uint32_t begin, end; int tid; } pf_job;
+static void *pf_thread(void *p) { pf_job *j = (pf_job *)p; j->fn(j->ctx, j->begin, j->end, j->tid); return NULL; }
+static void parallel_for(uint32_t n, int n_threads, pf_body fn, void *ctx) {
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    if ((uint32_t)n_threads > n) n_threads = n ? (int)n : 1;
+    if (n_threads == 1) { fn(ctx, 0, n, 0); return; }
+    pthread_t th[256]; pf_job jobs[256];
+    for (int i = 0; i < n_threads; i++) {
+        jobs[i].fn = fn; jobs[i].ctx = ctx; jobs[i].tid = i;
+        jobs[i].begin = (uint32_t)((uint64_t)n * i / n_threads);
+        jobs[i].end = (uint32_t)((uint64_t)n * (i + 1) / n_threads);
+        pthread_create(&th[i], NULL, pf_thread, &jobs[i]);
+    }
+    for (int i = 0; i < n_threads; i++) pthread_join(th[i], NULL);
+}
+
+/* ------------------------------------------------------------------------------------------------ RNG */
+/* random.slang:5-15 (Bob Jenkins' integer hash) */
+uint32_t orc_hash(uint32_t a) {
+    a = (a + 0x7ed55d16u) + (a << 12);
+    a = (a ^ 0xc761c23cu) ^ (a >> 19);
+    a = (a + 0x165667b1u) + (a << 5);
+    a = (a + 0xd3a2646cu) ^ (a << 9);
+    a = (a + 0xfd7046c5u) + (a << 3);
+    a = (a ^ 0xb55a4f09u) ^ (a >> 16);
+    return a;
+}
+/* math.slang:105-112 */
+static uint32_t integer_explode(uint32_t x) {
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+/* math.slang:114-117 */
+uint32_t orc_zcurve(uint32_t x, uint32_t y) { return integer_explode(x) | (integer_explode(y) << 1); }
+/* random.slang:42-46 */
+uint32_t orc_rng_seed(uint32_t px, uint32_t py, uint32_t frame) { return orc_hash(orc_zcurve(px, py)) + frame; }
+/* random.slang:49-79 : one-block murmur3 of the counter, len = 4 finaliser.  Counter-based: `index` is explicit. */
+uint32_t orc_murmur3(uint32_t seed, uint32_t index) {
+    const uint32_t c1 = 0xcc9e2d51u, c2 = 0x1b873593u;
+    uint32_t h = seed, k = index;
+    k *= c1;
+    k = (k << 15) | (k >> 17);
+    k *= c2;
+    h ^= k;
+    h = ((h << 13) | (h >> 19)) * 5u + 0xe6546b64u;
+    h ^= 4u;
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+/* random.slang:82-89 */
+float orc_uniform_float(uint32_t seed, uint32_t index) {
+    uint32_t v = orc_murmur3(seed, index);
+    return u2f((v & 0x7FFFFFu) | 0x3F800000u) - 1.0f;
+}
+/* random.slang:17-24 (bit reversal part; the float scale is trivial) */
+uint32_t orc_radical_inverse_bits(uint32_t bits) {
+    bits = (bits << 16) | (bits >> 16);
+    bits = ((bits & 0x55555555u) << 1) | ((bits & 0xAAAAAAAAu) >> 1);
+    bits = ((bits & 0x33333333u) << 2) | ((bits & 0xCCCCCCCCu) >> 2);
+    bits = ((bits & 0x0F0F0F0Fu) << 4) | ((bits & 0xF0F0F0F0u) >> 4);
+    bits = ((bits & 0x00FF00FFu) << 8) | ((bits & 0xFF00FF00u) >> 8);
+    return bits;
+}
+
+/* ------------------------------------------------------------------------------------------------ packing */
+/* packing.slang:2-10 */
+static float unpack_unorm(uint32_t p, uint32_t bits) {
+    uint32_t maxv = (1u << bits) - 1u;
+    return (float)(p & maxv) / (float)maxv;
+}
+static uint32_t pack_unorm(float v, uint32_t bits) {
+    uint32_t maxv = (1u << bits) - 1u;
+    float c = fminx(fmaxx(v, 0.0f), 1.0f);
+    return (uint32_t)(c * (float)maxv + 0.5f);
+}
+/* packing.slang:12-18 */
+uint32_t orc_pack_normal_11_10_11(const float n[3]) {
+    uint32_t p = 0;
+    p += pack_unorm(n[0] * 0.5f + 0.5f, 11);
+    p += pack_unorm(n[1] * 0.5f + 0.5f, 10) << 11;
+    p += pack_unorm(n[2] * 0.5f + 0.5f, 11) << 21;
+    return p;
+}
+/* packing.slang:20-27 */
+void orc_unpack_normal_11_10_11(uint32_t p, float n[3]) {
+    n[0] = unpack_unorm(p, 11) * 2.0f - 1.0f;
+    n[1] = unpack_unorm(p >> 11, 10) * 2.0f - 1.0f;
+    n[2] = unpack_unorm(p >> 21, 11) * 2.0f - 1.0f;
+    normalize3(n);
+}
+/* packing.slang:46-53 */
+uint32_t orc_pack_color_888(const float c[3]) {
+    uint32_t p = 0;
+    p += pack_unorm(sqrtf(c[0]), 8);
+    p += pack_unorm(sqrtf(c[1]), 8) << 8;
+    p += pack_unorm(sqrtf(c[2]), 8) << 16;
+    return p;
+}
+/* packing.slang:55-62 */
+void orc_unpack_color_888(uint32_t p, float c[3]) {
+    float r = unpack_unorm(p, 8), g = unpack_unorm(p >> 8, 8), b = unpack_unorm(p >> 16, 8);
+    c[0] = r * r; c[1] = g * g; c[2] = b * b;
+}
+/* f32 -> f16 bits, round to nearest even (f32tof16, packing.slang:88-90) */
+static uint32_t f32_to_f16(float f) {
+    uint32_t x = f2u(f), sign = (x >> 16) & 0x8000u;
+    uint32_t em = x & 0x7FFFFFFFu;
+    if (em >= 0x7F800000u) return sign | (em > 0x7F800000u ? 0x7E00u : 0x7C00u);
+    if (em >= 0x477FF000u) return sign | 0x7C00u; /* rounds to >= 65520 -> inf */
+    if (em < 0x33000001u) return sign;            /* < 2^-25 (or == 2^-25 tie to even 0) -> 0 */
+    int32_t e = (int32_t)(em >> 23) - 127;
+    uint32_t m = (em & 0x7FFFFFu) | 0x800000u;
+    uint32_t shift, h;
+    if (e < -14) { /* subnormal half */
+        shift = (uint32_t)(13 + (-14 - e));
+        h = m >> shift;
+        uint32_t rem = m & ((1u << shift) - 1u), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (h & 1u))) h++;
+        return sign | h;
+    }
+    h = ((uint32_t)(e + 15) << 10) | ((m >> 13) & 0x3FFu);
+    uint32_t rem = m & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) h++;
+    return sign | h;
+}
+static float f16_to_f32(uint32_t h) {
+    uint32_t sign = (h & 0x8000u) << 16, e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
+    if (e == 0) {
+        if (m == 0) return u2f(sign);
+        float v = (float)m * 5.9604644775390625e-08f; /* 2^-24 */
+        return (sign ? -v : v);
+    }
+    if (e == 31) return u2f(sign | 0x7F800000u | (m << 13));
+    return u2f(sign | ((e + 112u) << 23) | (m << 13));
+}
+/* packing.slang:88-97 */
+uint32_t orc_pack_2x16f(float a, float b) { return f32_to_f16(a) | (f32_to_f16(b) << 16); }
+void orc_unpack_2x16f(uint32_t u, float out[2]) { out[0] = f16_to_f32(u & 0xFFFFu); out[1] = f16_to_f32((u >> 16) & 0xFFFFu); }
+
+static float exp2i(int e) { return u2f((uint32_t)(e + 127) << 23); } /* exact 2^e, -126 <= e <= 127 */
+/* packing.slang:99-144 */
+uint32_t orc_float3_to_rgb9e5(const float c[3]) {
+    const float max_rgb9e5 = (511.0f / 512.0f) * 65536.0f;
+    float rc = fminx(fmaxx(c[0], 0.0f), max_rgb9e5);
+    float gc = fminx(fmaxx(c[1], 0.0f), max_rgb9e5);
+    float bc = fminx(fmaxx(c[2], 0.0f), max_rgb9e5);
+    float maxrgb = fmaxx(rc, fmaxx(gc, bc));
+    int fl2 = (int)((f2u(maxrgb) & 0x7F800000u) >> 23) - 127; /* floor_log2, packing.slang:115-119 */
+    int exp_shared = (fl2 > -16 ? fl2 : -16) + 1 + 15;
+    float denom = exp2i(exp_shared - 15 - 9);
+    int maxm = (int)floorf(maxrgb / denom + 0.5f);
+    if (maxm == 512) { denom *= 2.0f; exp_shared += 1; }
+    int rm = (int)floorf(rc / denom + 0.5f);
+    int gm = (int)floorf(gc / denom + 0.5f);
+    int bm = (int)floorf(bc / denom + 0.5f);
+    return ((uint32_t)rm << 23) | ((uint32_t)gm << 14) | ((uint32_t)bm << 5) | (uint32_t)exp_shared;
+}
+/* packing.slang:146-162 */
+void orc_rgb9e5_to_float3(uint32_t v, float c[3]) {
+    int e = (int)(v & 31u) - 15 - 9;
+    float scale = exp2i(e);
+    c[0] = (float)((v >> 23) & 511u) * scale;
+    c[1] = (float)((v >> 14) & 511u) * scale;
+    c[2] = (float)((v >> 5) & 511u) * scale;
+}
+/* gbuffer_helpers.slang:22-34 (roughness -> perceptual: sqrt, :73-75) */
+void orc_gbuffer_pack(const float s[11], uint32_t out[4]) {
+    out[0] = orc_pack_color_888(s + 0);
+    out[1] = orc_pack_normal_11_10_11(s + 6);
+    out[2] = orc_pack_2x16f(sqrtf(s[9]), s[10]);
+    out[3] = orc_float3_to_rgb9e5(s + 3);
+}
+/* gbuffer_helpers.slang:59-70 (perceptual -> roughness: r*r, :77-79) */
+void orc_gbuffer_unpack(const uint32_t in[4], float s[11]) {
+    float rm[2];
+    orc_unpack_color_888(in[0], s + 0);
+    orc_unpack_normal_11_10_11(in[1], s + 6);
+    orc_unpack_2x16f(in[2], rm);
+    s[9] = rm[0] * rm[0];
+    s[10] = rm[1];
+    orc_rgb9e5_to_float3(in[3], s + 3);
+}
+
+/* ------------------------------------------------------------------------------------------------ math */
+/* [arithmetic contract] sin(2 pi u), cos(2 pi u) for u in [0,1): exact quadrant reduction + Taylor/Horner on
+ * [0, pi/4].  Stands in for sin()/cos() of brdf.slang:61-62 so that CPU and GPU agree bit for bit. */
+void orc_sincos_2pi(float u, float *so, float *co) {
+    float x = u * 4.0f;
+    int q = (int)x;
+    float r = x - (float)q;
+    int swap = r > 0.5f;
+    if (swap) r = 1.0f - r;
+    float a = r * F_HALF_PI, a2 = a * a;
+    float s = a * (1.0f + a2 * (-1.6666667163e-01f + a2 * (8.3333337680e-03f + a2 * (-1.9841270114e-04f + a2 * 2.7557314297e-06f))));
+    float c = 1.0f + a2 * (-0.5f + a2 * (4.1666667908e-02f + a2 * (-1.3888889225e-03f + a2 * (2.4801587642e-05f + a2 * -2.7557314297e-07f))));
+    if (swap) { float t = s; s = c; c = t; }
+    switch (q & 3) {
+        case 0: *so = s; *co = c; break;
+        case 1: *so = c; *co = -s; break;
+        case 2: *so = -s; *co = -c; break;
+        default: *so = -c; *co = s; break;
+    }
+}
+/* [arithmetic contract] atan2 through a degree-11 odd polynomial on [0,1] (max error ~1e-5 rad) */
+float orc_atan2(float y, float x) {
+    float ax = x < 0.0f ? -x : x, ay = y < 0.0f ? -y : y;
+    float mx = fmaxx(ax, ay), mn = fminx(ax, ay);
+    if (mx == 0.0f) return 0.0f;
+    float a = mn / mx, s = a * a;
+    float r = a * (0.99997726f + s * (-0.33262347f + s * (0.19354346f + s * (-0.11643287f + s * (0.05265332f + s * -0.01172120f)))));
+    if (ay > ax) r = F_HALF_PI - r;
+    if (x < 0.0f) r = F_PI - r;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+/* math.slang:6-12 ; asin(y) := atan2(y, sqrt(1 - y^2)) */
+void orc_dir_to_equirect_uv(const float d[3], float uv[2]) {
+    float as = orc_atan2(d[1], sqrtf(fmaxx(0.0f, 1.0f - d[1] * d[1])));
+    uv[0] = 0.5f + orc_atan2(d[2], d[0]) / F_TAU;
+    uv[1] = 0.5f - as / F_PI;
+}
+/* math.slang:29-50 ; returns the basis columns b1,b2 (third column is n) */
+void orc_onb(const float n[3], float b1[3], float b2[3]) {
+    if (n[2] < 0.0f) {
+        const float a = 1.0f / (1.0f - n[2]);
+        const float b = n[0] * n[1] * a;
+        b1[0] = 1.0f - n[0] * n[0] * a; b1[1] = -b; b1[2] = n[0];
+        b2[0] = b; b2[1] = n[1] * n[1] * a - 1.0f; b2[2] = -n[1];
+    } else {
+        const float a = 1.0f / (1.0f + n[2]);
+        const float b = -n[0] * n[1] * a;
+        b1[0] = 1.0f - n[0] * n[0] * a; b1[1] = b; b1[2] = -n[0];
+        b2[0] = b; b2[1] = 1.0f - n[1] * n[1] * a; b2[2] = -n[1];
+    }
+}
+/* mul(tangent_to_world, wi), refrence_mode.slang:48 with the matrix of math.slang:45-49 */
+static void onb_apply(const float b1[3], const float b2[3], const float n[3], const float w[3], float o[3]) {
+    o[0] = b1[0] * w[0] + b2[0] * w[1] + n[0] * w[2];
+    o[1] = b1[1] * w[0] + b2[1] * w[1] + n[1] * w[2];
+    o[2] = b1[2] * w[0] + b2[2] * w[1] + n[2] * w[2];
+}
+/* brdf.slang:56-65 : DiffuseBrdf.sample direction (pdf = 1/pi projected-solid-angle, value_over_pdf = albedo) */
+void orc_diffuse_sample(float u0, float u1, float wi[3]) {
+    float sp, cp;
+    orc_sincos_2pi(u0, &sp, &cp); /* phi = urand.x * TAU */
+    float cos_theta = sqrtf(fmaxx(0.0f, 1.0f - u1));
+    float sin_theta = sqrtf(fmaxx(0.0f, 1.0f - cos_theta * cos_theta));
+    wi[0] = cp * sin_theta; wi[1] = sp * sin_theta; wi[2] = cos_theta;
+}
+
+/* postprocess.slang:13-88 (AGX_LOOK 2 "Punchy"; pow() of a negative base clamped to 0 -- documented deviation) */
+static float agx_contrast(float x) { /* :13-25 */
+    float x2 = x * x, x4 = x2 * x2;
+    return 15.5f * x4 * x2 - 40.14f * x4 * x + 31.96f * x4 - 6.868f * x2 * x + 0.4298f * x2 + 0.1191f * x - 0.00232f;
+}
+void orc_agx_tonemap(const float in[3], float out[3]) {
+    static const float m[9] = {0.842479062253094f, 0.0423282422610123f, 0.0423756549057051f,
+                               0.0784335999999992f, 0.878468636469772f, 0.0784336f,
+                               0.0792237451477643f, 0.0791661274605434f, 0.879142973793104f};
+    static const float mi[9] = {1.19687900512017f, -0.0528968517574562f, -0.0529716355144438f,
+                                -0.0980208811401368f, 1.15190312990417f, -0.0980434501171241f,
+                                -0.0990297440797205f, -0.0989611768448433f, 1.15107367264116f};
+    const float min_ev = -12.47393f, max_ev = 4.026069f;
+    float v[3], w[3];
+    for (int j = 0; j < 3; j++) v[j] = in[0] * m[0 * 3 + j] + in[1] * m[1 * 3 + j] + in[2] * m[2 * 3 + j]; /* mul(val, agx_mat) :35 */
+    for (int j = 0; j < 3; j++) {
+        float l = v[j] > 0.0f ? log2f(v[j]) : min_ev;
+        l = fminx(fmaxx(l, min_ev), max_ev);
+        l = (l - min_ev) / (max_ev - min_ev);
+        v[j] = agx_contrast(l);
+    }
+    /* agxLook :62-88 */
+    float luma = v[0] * 0.2126f + v[1] * 0.7152f + v[2] * 0.0722f;
+    for (int j = 0; j < 3; j++) {
+        float p = powf(fmaxx(v[j], 0.0f), 1.1f);
+        w[j] = luma + 1.1f * (p - luma);
+    }
+    /* agxEotf :47-60 */
+    for (int j = 0; j < 3; j++) out[j] = w[0] * mi[0 * 3 + j] + w[1] * mi[1 * 3 + j] + w[2] * mi[2 * 3 + j];
+}
+
+/* ------------------------------------------------------------------------------------------------ camera */
+/* column-major 4x4: m[c*4+r] */
+static void mat4_mul_vec(const float m[16], const float v[4], float o[4]) {
+    for (int r = 0; r < 4; r++) o[r] = m[0 + r] * v[0] + m[4 + r] * v[1] + m[8 + r] * v[2] + m[12 + r] * v[3];
+}
+static void mat4_inverse(const float m[16], float inv[16]) { /* glam Mat4::inverse restated as a plain cofactor expansion */
+    double a[16], o[16];
+    for (int i = 0; i < 16; i++) a[i] = m[i];
+    o[0] = a[5] * a[10] * a[15] - a[5] * a[11] * a[14] - a[9] * a[6] * a[15] + a[9] * a[7] * a[14] + a[13] * a[6] * a[11] - a[13] * a[7] * a[10];
+    o[4] = -a[4] * a[10] * a[15] + a[4] * a[11] * a[14] + a[8] * a[6] * a[15] - a[8] * a[7] * a[14] - a[12] * a[6] * a[11] + a[12] * a[7] * a[10];
+    o[8] = a[4] * a[9] * a[15] - a[4] * a[11] * a[13] - a[8] * a[5] * a[15] + a[8] * a[7] * a[13] + a[12] * a[5] * a[11] - a[12] * a[7] * a[9];
+    o[12] = -a[4] * a[9] * a[14] + a[4] * a[10] * a[13] + a[8] * a[5] * a[14] - a[8] * a[6] * a[13] - a[12] * a[5] * a[10] + a[12] * a[6] * a[9];
+    o[1] = -a[1] * a[10] * a[15] + a[1] * a[11] * a[14] + a[9] * a[2] * a[15] - a[9] * a[3] * a[14] - a[13] * a[2] * a[11] + a[13] * a[3] * a[10];
+    o[5] = a[0] * a[10] * a[15] - a[0] * a[11] * a[14] - a[8] * a[2] * a[15] + a[8] * a[3] * a[14] + a[12] * a[2] * a[11] - a[12] * a[3] * a[10];
+    o[9] = -a[0] * a[9] * a[15] + a[0] * a[11] * a[13] + a[8] * a[1] * a[15] - a[8] * a[3] * a[13] - a[12] * a[1] * a[11] + a[12] * a[3] * a[9];
+    o[13] = a[0] * a[9] * a[14] - a[0] * a[10] * a[13] - a[8] * a[1] * a[14] + a[8] * a[2] * a[13] + a[12] * a[1] * a[10] - a[12] * a[2] * a[9];
+    o[2] = a[1] * a[6] * a[15] - a[1] * a[7] * a[14] - a[5] * a[2] * a[15] + a[5] * a[3] * a[14] + a[13] * a[2] * a[7] - a[13] * a[3] * a[6];
+    o[6] = -a[0] * a[6] * a[15] + a[0] * a[7] * a[14] + a[4] * a[2] * a[15] - a[4] * a[3] * a[14] - a[12] * a[2] * a[7] + a[12] * a[3] * a[6];
+    o[10] = a[0] * a[5] * a[15] - a[0] * a[7] * a[13] - a[4] * a[1] * a[15] + a[4] * a[3] * a[13] + a[12] * a[1] * a[7] - a[12] * a[3] * a[5];
+    o[14] = -a[0] * a[5] * a[14] + a[0] * a[6] * a[13] + a[4] * a[1] * a[14] - a[4] * a[2] * a[13] - a[12] * a[1] * a[6] + a[12] * a[2] * a[5];
+    o[3] = -a[1] * a[6] * a[11] + a[1] * a[7] * a[10] + a[5] * a[2] * a[11] - a[5] * a[3] * a[10] - a[9] * a[2] * a[7] + a[9] * a[3] * a[6];
+    o[7] = a[0] * a[6] * a[11] - a[0] * a[7] * a[10] - a[4] * a[2] * a[11] + a[4] * a[3] * a[10] + a[8] * a[2] * a[7] - a[8] * a[3] * a[6];
+    o[11] = -a[0] * a[5] * a[11] + a[0] * a[7] * a[9] + a[4] * a[1] * a[11] - a[4] * a[3] * a[9] - a[8] * a[1] * a[7] + a[8] * a[3] * a[5];
+    o[15] = a[0] * a[5] * a[10] - a[0] * a[6] * a[9] - a[4] * a[1] * a[10] + a[4] * a[2] * a[9] + a[8] * a[1] * a[6] - a[8] * a[2] * a[5];
+    double det = a[0] * o[0] + a[1] * o[4] + a[2] * o[8] + a[3] * o[12];
+    double id = 1.0 / det;
+    for (int i = 0; i < 16; i++) inv[i] = (float)(o[i] * id);
+}
+/* camera.rs:52-58 (glam look_at_rh / perspective_rh, depth 0..1) + renderer/mod.rs:72-78.
+ * "parity unpinned": glam is a third-party crate (0.29.3) absent from /root/reference; closed forms restated. */
+void orc_camera_gconst(const float pos[3], const float dir_in[3], float fov_y, float aspect, float z_near,
+                       float z_far, float width, float height, orc_gconst *g) {
+    memset(g, 0, sizeof(*g));
+    float f[3] = {dir_in[0], dir_in[1], dir_in[2]}, up[3] = {0.0f, 1.0f, 0.0f}, s[3], u[3];
+    normalize3(f); /* Camera::new normalises direction, camera.rs:43 */
+    cross3(f, up, s);
+    normalize3(s);
+    cross3(s, f, u);
+    float *v = g->view;
+    v[0] = s[0]; v[1] = u[0]; v[2] = -f[0]; v[3] = 0.0f;
+    v[4] = s[1]; v[5] = u[1]; v[6] = -f[1]; v[7] = 0.0f;
+    v[8] = s[2]; v[9] = u[2]; v[10] = -f[2]; v[11] = 0.0f;
+    v[12] = -dot3(pos, s); v[13] = -dot3(pos, u); v[14] = dot3(pos, f); v[15] = 1.0f;
+    float sf = (float)sin(0.5 * (double)fov_y), cf = (float)cos(0.5 * (double)fov_y);
+    float h = cf / sf, w = h / aspect, r = z_far / (z_near - z_far);
+    float *p = g->proj;
+    p[0] = w; p[5] = h; p[10] = r; p[11] = -1.0f; p[14] = r * z_near;
+    mat4_inverse(g->proj, g->proj_inverse);
+    mat4_inverse(g->view, g->view_inverse);
+    g->window_size[0] = width; g->window_size[1] = height;
+    g->blendfactor = 1.0f;
+}
+/* gbuffer_helpers.slang:85-103 with PlanarViewConstants := {proj_inverse, view_inverse, window_size, view_inverse col 3}.
+ * Pixel (0,0) is top-left and d.y is flipped so images are upright (documented deviation). */
+void orc_primary_ray(const orc_gconst *g, uint32_t px, uint32_t py, float o[3], float d[3]) {
+    float cx = ((float)px + 0.5f) / g->window_size[0], cy = ((float)py + 0.5f) / g->window_size[1];
+    float clip[4] = {cx * 2.0f - 1.0f, -(cy * 2.0f - 1.0f), 1.0f, 1.0f}, target[4], dir4[4], w[4];
+    mat4_mul_vec(g->proj_inverse, clip, target);
+    float t3[3] = {target[0], target[1], target[2]};
+    normalize3(t3);
+    dir4[0] = t3[0]; dir4[1] = t3[1]; dir4[2] = t3[2]; dir4[3] = 0.0f;
+    mat4_mul_vec(g->view_inverse, dir4, w);
+    d[0] = w[0]; d[1] = w[1]; d[2] = w[2];
+    o[0] = g->view_inverse[12]; o[1] = g->view_inverse[13]; o[2] = g->view_inverse[14];
+}
+
+/* ------------------------------------------------------------------------------------------------ scene */
+struct orc_scene {
+    float *verts; uint32_t n_verts;      /* interleaved 8 floats */
+    uint32_t *indices; uint32_t n_indices;
+    orc_geometry_info *geoms; uint32_t *prim_counts, *first_prim; uint32_t n_geoms;
+    uint32_t n_prims; uint32_t *prim_geom;
+    /* accel */
+    uint32_t n_tris, n_nodes, max_depth;
+    float *nodes;   /* 16 words per node */
+    float *tris;    /* 12 words per tri (Morton order) */
+    uint64_t *codes;
+    /* sky */
+    float *sky; uint32_t sky_w, sky_h;
+    float *cdf_cond, *cdf_marg, *pdf_uv;
+    /* blue noise */
+    uint8_t *bn; uint32_t bn_w, bn_h;
+};
+
+orc_scene *orc_scene_create(void) { return (orc_scene *)calloc(1, sizeof(orc_scene)); }
+static void accel_free(orc_scene *s) {
+    free(s->nodes); free(s->tris); free(s->codes);
+    s->nodes = s->tris = NULL; s->codes = NULL; s->n_tris = s->n_nodes = 0;
+}
+void orc_scene_destroy(orc_scene *s) {
+    if (!s) return;
+    accel_free(s);
+    free(s->verts); free(s->indices); free(s->geoms); free(s->prim_counts); free(s->first_prim); free(s->prim_geom);
+    free(s->sky); free(s->cdf_cond); free(s->cdf_marg); free(s->pdf_uv); free(s->bn);
+    free(s);
+}
+int orc_scene_set_vertices(orc_scene *s, const float *pnt, uint32_t n) {
+    free(s->verts);
+    s->verts = (float *)malloc((size_t)n * 32 + 4);
+    memcpy(s->verts, pnt, (size_t)n * 32);
+    s->n_verts = n;
+    return 0;
+}
+int orc_scene_set_indices(orc_scene *s, const uint32_t *idx, uint32_t n) {
+    free(s->indices);
+    s->indices = (uint32_t *)malloc((size_t)n * 4 + 4);
+    memcpy(s->indices, idx, (size_t)n * 4);
+    s->n_indices = n;
+    return 0;
+}
+int orc_scene_set_geometry(orc_scene *s, const orc_geometry_info *g, const uint32_t *prim_counts, uint32_t n) {
+    free(s->geoms); free(s->prim_counts); free(s->first_prim); free(s->prim_geom);
+    s->geoms = (orc_geometry_info *)malloc((size_t)n * sizeof(*g) + 4);
+    memcpy(s->geoms, g, (size_t)n * sizeof(*g));
+    s->prim_counts = (uint32_t *)malloc((size_t)n * 4 + 4);
+    s->first_prim = (uint32_t *)malloc((size_t)n * 4 + 4);
+    uint32_t total = 0;
+    for (uint32_t i = 0; i < n; i++) { s->prim_counts[i] = prim_counts[i]; s->first_prim[i] = total; total += prim_counts[i]; }
+    s->n_geoms = n; s->n_prims = total;
+    s->prim_geom = (uint32_t *)malloc((size_t)total * 4 + 4);
+    for (uint32_t i = 0; i < n; i++)
+        for (uint32_t k = 0; k < prim_counts[i]; k++) s->prim_geom[s->first_prim[i] + k] = i;
+    return 0;
+}
+int orc_scene_set_bluenoise(orc_scene *s, const uint8_t *rgba, uint32_t w, uint32_t h) {
+    free(s->bn);
+    s->bn = (uint8_t *)malloc((size_t)w * h * 4);
+    memcpy(s->bn, rgba, (size_t)w * h * 4);
+    s->bn_w = w; s->bn_h = h;
+    return 0;
+}
+/* math.slang:119-122 */
+static float luminance3(const float c[3]) { return c[0] * 0.299f + c[1] * 0.587f + c[2] * 0.114f; }
+/* [north_star] sky importance tables: f = luminance * sin(theta) per texel, conditional CDF per row, marginal CDF
+ * over rows, pdf in (u,v) space.  Built in double, stored as float. */
+int orc_scene_set_sky(orc_scene *s, const float *rgb, uint32_t w, uint32_t h) {
+    free(s->sky); free(s->cdf_cond); free(s->cdf_marg); free(s->pdf_uv);
+    size_t n = (size_t)w * h;
+    s->sky = (float *)malloc(n * 12);
+    memcpy(s->sky, rgb, n * 12);
+    s->sky_w = w; s->sky_h = h;
+    s->cdf_cond = (float *)malloc(n * 4);
+    s->pdf_uv = (float *)malloc(n * 4);
+    s->cdf_marg = (float *)malloc((size_t)h * 4);
+    double *rowsum = (double *)malloc((size_t)h * 8), total = 0.0;
+    for (uint32_t y = 0; y < h; y++) {
+        double st = sin(3.14159265358979323846 * ((double)y + 0.5) / (double)h), acc = 0.0;
+        for (uint32_t x = 0; x < w; x++) {
+            double f = ((double)luminance3(rgb + 3 * ((size_t)y * w + x)) + 1e-6) * st;
+            s->pdf_uv[(size_t)y * w + x] = (float)f; /* temporarily the unnormalised density */
+            acc += f;
+            s->cdf_cond[(size_t)y * w + x] = (float)acc; /* normalised below */
+        }
+        rowsum[y] = acc;
+        total += acc;
+    }
+    double acc = 0.0;
+    for (uint32_t y = 0; y < h; y++) {
+        float inv = (float)(1.0 / rowsum[y]);
+        for (uint32_t x = 0; x < w; x++) s->cdf_cond[(size_t)y * w + x] *= inv;
+        s->cdf_cond[(size_t)y * w + w - 1] = 1.0f;
+        acc += rowsum[y];
+        s->cdf_marg[y] = (float)(acc / total);
+    }
+    s->cdf_marg[h - 1] = 1.0f;
+    float norm = (float)((double)w * (double)h / total);
+    for (size_t i = 0; i < n; i++) s->pdf_uv[i] *= norm;
+    free(rowsum);
+    return 0;
+}
+const float *orc_sky_cdf_cond(const orc_scene *s) { return s->cdf_cond; }
+const float *orc_sky_cdf_marg(const orc_scene *s) { return s->cdf_marg; }
+const float *orc_sky_pdf_uv(const orc_scene *s) { return s->pdf_uv; }
+
+/* ------------------------------------------------------------------------------------------------ LBVH [north_star] */
+/* Replaces create_acceleration_structure (raytracing.rs:88-148): 63-bit Morton codes of the triangle-box centres,
+ * sort by (code, primitive), Karras 2012 radix-tree topology, bottom-up boxes, 64 B two-child-box nodes. */
+static uint64_t expand21(uint32_t v) {
+    uint64_t x = v & 0x1FFFFFu;
+    x = (x | (x << 32)) & 0x001F00000000FFFFull;
+    x = (x | (x << 16)) & 0x001F0000FF0000FFull;
+    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+static void tri_positions(const orc_scene *s, uint32_t prim, float a[3], float b[3], float c[3]) {
+    uint32_t g = s->prim_geom[prim], local = prim - s->first_prim[g];
+    const orc_geometry_info *gi = &s->geoms[g];
+    uint32_t io = gi->index_offset + 3u * local;
+    const float *v0 = s->verts + 8 * (size_t)(gi->vertex_offset + s->indices[io]);
+    const float *v1 = s->verts + 8 * (size_t)(gi->vertex_offset + s->indices[io + 1]);
+    const float *v2 = s->verts + 8 * (size_t)(gi->vertex_offset + s->indices[io + 2]);
+    for (int k = 0; k < 3; k++) { a[k] = v0[k]; b[k] = v1[k]; c[k] = v2[k]; }
+}
+typedef struct { uint64_t code; uint32_t prim; } code_prim;
+static int cmp_code_prim(const void *pa, const void *pb) {
+    const code_prim *a = (const code_prim *)pa, *b = (const code_prim *)pb;
+    if (a->code != b->code) return a->code < b->code ? -1 : 1;
+    return a->prim < b->prim ? -1 : (a->prim > b->prim ? 1 : 0);
+}
+static int delta_fn(const uint64_t *codes, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    uint64_t a = codes[i], b = codes[j];
+    if (a != b) return __builtin_clzll(a ^ b);
+    return 64 + __builtin_clz((uint32_t)i ^ (uint32_t)j);
+}
+int orc_accel_build(orc_scene *s) {
+    accel_free(s);
+    uint32_t n = s->n_prims;
+    s->n_tris = n;
+    if (n == 0) return 0;
+    float *bmin = (float *)malloc((size_t)n * 12), *bmax = (float *)malloc((size_t)n * 12);
+    float cmin[3] = {INFINITY, INFINITY, INFINITY}, cmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float smin[3] = {INFINITY, INFINITY, INFINITY}, smax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = 0; i < n; i++) {
+        float a[3], b[3], c[3];
+        tri_positions(s, i, a, b, c);
+        for (int k = 0; k < 3; k++) {
+            float lo = fminx(a[k], fminx(b[k], c[k])), hi = fmaxx(a[k], fmaxx(b[k], c[k]));
+            bmin[3 * i + k] = lo; bmax[3 * i + k] = hi;
+            float ce = (lo + hi) * 0.5f;
+            cmin[k] = fminx(cmin[k], ce); cmax[k] = fmaxx(cmax[k], ce);
+            smin[k] = fminx(smin[k], lo); smax[k] = fmaxx(smax[k], hi);
+        }
+    }
+    /* conservative leaf padding so that the slab test never culls a triangle the fp32 triangle test accepts */
+    float ext = fmaxx(smax[0] - smin[0], fmaxx(smax[1] - smin[1], smax[2] - smin[2]));
+    float pad = ext * 1.0e-5f;
+    code_prim *cp = (code_prim *)malloc((size_t)n * sizeof(code_prim));
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t q[3];
+        for (int k = 0; k < 3; k++) {
+            float e = cmax[k] - cmin[k];
+            float ce = (bmin[3 * i + k] + bmax[3 * i + k]) * 0.5f;
+            float nrm = e > 0.0f ? (ce - cmin[k]) / e : 0.0f;
+            float qf = fminx(nrm * 2097152.0f, 2097151.0f);
+            q[k] = (uint32_t)qf;
+        }
+        cp[i].code = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
+        cp[i].prim = i;
+    }
+    qsort(cp, n, sizeof(code_prim), cmp_code_prim);
+    s->codes = (uint64_t *)malloc((size_t)n * 8);
+    s->tris = (float *)calloc((size_t)n * 12, 4);
+    float *lmin = (float *)malloc((size_t)n * 12), *lmax = (float *)malloc((size_t)n * 12);
+    for (uint32_t k = 0; k < n; k++) {
+        uint32_t p = cp[k].prim;
+        s->codes[k] = cp[k].code;
+        float a[3], b[3], c[3];
+        tri_positions(s, p, a, b, c);
+        float *t = s->tris + 12 * (size_t)k;
+        t[0] = a[0]; t[1] = a[1]; t[2] = a[2];
+        t[3] = b[0] - a[0]; t[4] = b[1] - a[1]; t[5] = b[2] - a[2];
+        t[6] = c[0] - a[0]; t[7] = c[1] - a[1]; t[8] = c[2] - a[2];
+        t[9] = u2f(p); t[10] = 0.0f; t[11] = 0.0f;
+        for (int j = 0; j < 3; j++) { lmin[3 * k + j] = bmin[3 * p + j] - pad; lmax[3 * k + j] = bmax[3 * p + j] + pad; }
+    }
+    uint32_t nn = n > 1 ? n - 1 : 1;
+    s->n_nodes = nn;
+    s->nodes = (float *)calloc((size_t)nn * 16, 4);
+    if (n == 1) {
+        float *nd = s->nodes;
+        for (int j = 0; j < 3; j++) { nd[j] = lmin[j]; nd[3 + j] = lmax[j]; nd[6 + j] = INFINITY; nd[9 + j] = -INFINITY; }
+        nd[12] = u2f(0x80000000u); nd[13] = u2f(0x80000000u);
+        s->max_depth = 1;
+    } else {
+        int32_t *left = (int32_t *)malloc((size_t)nn * 4), *right = (int32_t *)malloc((size_t)nn * 4);
+        const uint64_t *codes = s->codes;
+        int N = (int)n;
+        for (int i = 0; i < N - 1; i++) { /* Karras 2012, Algorithm "construct internal node i" */
+            int d = (delta_fn(codes, N, i, i + 1) - delta_fn(codes, N, i, i - 1)) >= 0 ? 1 : -1;
+            int dmin = delta_fn(codes, N, i, i - d);
+            int lmaxv = 2;
+            while (delta_fn(codes, N, i, i + lmaxv * d) > dmin) lmaxv *= 2;
+            int l = 0;
+            for (int t = lmaxv / 2; t >= 1; t /= 2)
+                if (delta_fn(codes, N, i, i + (l + t) * d) > dmin) l += t;
+            int j = i + l * d;
+            int dnode = delta_fn(codes, N, i, j);
+            int sp = 0, t = l;
+            do {
+                t = (t + 1) >> 1;
+                if (delta_fn(codes, N, i, i + (sp + t) * d) > dnode) sp += t;
+            } while (t > 1);
+            int gamma = i + sp * d + (d < 0 ? d : 0);
+            int lo = i < j ? i : j, hi = i < j ? j : i;
+            left[i] = (lo == gamma) ? (int32_t)(0x80000000u | (uint32_t)gamma) : gamma;
+            right[i] = (hi == gamma + 1) ? (int32_t)(0x80000000u | (uint32_t)(gamma + 1)) : gamma + 1;
+        }
+        /* boxes: iterative post-order from the root (node 0) */
+        float *nmin = (float *)malloc((size_t)nn * 12), *nmax = (float *)malloc((size_t)nn * 12);
+        uint32_t *stack = (uint32_t *)malloc((size_t)nn * 2 * 4 + 64);
+        uint8_t *state = (uint8_t *)calloc(nn, 1);
+        uint32_t *depth = (uint32_t *)calloc(nn, 4);
+        int sp = 0;
+        stack[sp++] = 0; depth[0] = 1;
+        uint32_t maxd = 1;
+        while (sp > 0) {
+            uint32_t i = stack[sp - 1];
+            if (!state[i]) {
+                state[i] = 1;
+                uint32_t l = (uint32_t)left[i], r = (uint32_t)right[i];
+                if (!(l & 0x80000000u)) { depth[l] = depth[i] + 1; stack[sp++] = l; }
+                if (!(r & 0x80000000u)) { depth[r] = depth[i] + 1; stack[sp++] = r; }
+                if (depth[i] + 1 > maxd) maxd = depth[i] + 1;
+            } else {
+                sp--;
+                uint32_t ch[2] = {(uint32_t)left[i], (uint32_t)right[i]};
+                float *nd = s->nodes + 16 * (size_t)i;
+                for (int c = 0; c < 2; c++) {
+                    const float *mn, *mx;
+                    if (ch[c] & 0x80000000u) { uint32_t k = ch[c] & 0x7FFFFFFFu; mn = lmin + 3 * k; mx = lmax + 3 * k; }
+                    else { mn = nmin + 3 * ch[c]; mx = nmax + 3 * ch[c]; }
+                    for (int j = 0; j < 3; j++) { nd[6 * c + j] = mn[j]; nd[6 * c + 3 + j] = mx[j]; }
+                    nd[12 + c] = u2f(ch[c]);
+                }
+                for (int j = 0; j < 3; j++) { nmin[3 * i + j] = fminx(nd[j], nd[6 + j]); nmax[3 * i + j] = fmaxx(nd[3 + j], nd[9 + j]); }
+            }
+        }
+        s->max_depth = maxd;
+        free(left); free(right); free(nmin); free(nmax); free(stack); free(state); free(depth);
+    }
+    free(bmin); free(bmax); free(cp); free(lmin); free(lmax);
+    return 0;
+}
+uint32_t orc_accel_num_tris(const orc_scene *s) { return s->n_tris; }
+uint32_t orc_accel_num_nodes(const orc_scene *s) { return s->n_nodes; }
+const float *orc_accel_nodes(const orc_scene *s) { return s->nodes; }
+const float *orc_accel_tris(const orc_scene *s) { return s->tris; }
+const uint64_t *orc_accel_codes(const orc_scene *s) { return s->codes; }
+uint32_t orc_accel_max_depth(const orc_scene *s) { return s->max_depth; }
+
+/* ------------------------------------------------------------------------------------------------ traversal */
+typedef struct { float t, u, v; uint32_t prim; } hit_t;
+
+/* [north_star] Moeller-Trumbore on precomputed (v0,e1,e2); both faces hit (no cull flags: pipeline_cache/mod.rs:326-333
+ * registers a plain closest-hit group).  Acceptance: t > tmin and (t < best.t or (t == best.t and prim < best.prim)),
+ * which makes the closest hit independent of traversal order. */
+static inline void tri_test(const float *tr, const float o[3], const float d[3], float tmin, hit_t *best) {
+    const float *v0 = tr, *e1 = tr + 3, *e2 = tr + 6;
+    float pv[3], tv[3], qv[3];
+    cross3(d, e2, pv);
+    float det = dot3(e1, pv);
+    if (det == 0.0f) return;
+    float inv = 1.0f / det;
+    tv[0] = o[0] - v0[0]; tv[1] = o[1] - v0[1]; tv[2] = o[2] - v0[2];
+    float u = dot3(tv, pv) * inv;
+    if (!(u >= 0.0f && u <= 1.0f)) return;
+    cross3(tv, e1, qv);
+    float v = dot3(d, qv) * inv;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return;
+    float t = dot3(e2, qv) * inv;
+    uint32_t prim = f2u(tr[9]);
+    if (t > tmin && (t < best->t || (t == best->t && prim < best->prim))) { best->t = t; best->u = u; best->v = v; best->prim = prim; }
+}
+static inline float guard_inv(float d) {
+    float a = d < 0.0f ? -d : d;
+    float g = a < 1e-20f ? (d < 0.0f ? -1e-20f : 1e-20f) : d;
+    return 1.0f / g;
+}
+static inline int slab(const float *bx, const float o[3], const float inv[3], float tmin, float tbest, float *tn_out) {
+    float tn = tmin, tf = tbest;
+    for (int k = 0; k < 3; k++) {
+        float t0 = (bx[k] - o[k]) * inv[k], t1 = (bx[3 + k] - o[k]) * inv[k];
+        float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
+        tn = lo > tn ? lo : tn;
+        tf = hi < tf ? hi : tf;
+    }
+    *tn_out = tn;
+    return tn <= tf;
+}
+#define ORC_STACK 256
+/* closest hit; near child first (ties: child 0), far child pushed, no re-cull on pop */
+static void traverse(const orc_scene *s, const float o[3], const float d[3], float tmin, float tmax, int any,
+                     hit_t *out, uint32_t *cn, uint32_t *ct) {
+    hit_t best = {tmax, 0.0f, 0.0f, ORC_MISS};
+    uint32_t nn = 0, nt = 0;
+    if (s->n_tris) {
+        float inv[3] = {guard_inv(d[0]), guard_inv(d[1]), guard_inv(d[2])};
+        uint32_t stack[ORC_STACK]; int sp = 0;
+        uint32_t cur = 0;
+        for (;;) {
+            if (cur & 0x80000000u) {
+                nt++;
+                tri_test(s->tris + 12 * (size_t)(cur & 0x7FFFFFFFu), o, d, tmin, &best);
+                if (any && best.prim != ORC_MISS) break;
+                if (sp == 0) break;
+                cur = stack[--sp];
+                continue;
+            }
+            const float *nd = s->nodes + 16 * (size_t)cur;
+            nn++;
+            float tn0, tn1;
+            int h0 = slab(nd, o, inv, tmin, best.t, &tn0), h1 = slab(nd + 6, o, inv, tmin, best.t, &tn1);
+            uint32_t r0 = f2u(nd[12]), r1 = f2u(nd[13]);
+            if (h0 && h1) {
+                int near1 = tn1 < tn0;
+                stack[sp++] = near1 ? r0 : r1;
+                cur = near1 ? r1 : r0;
+            } else if (h0) cur = r0;
+            else if (h1) cur = r1;
+            else { if (sp == 0) break; cur = stack[--sp]; }
+        }
+    }
+    *out = best;
+    if (cn) *cn = nn;
+    if (ct) *ct = nt;
+}
+
+typedef struct {
+    const orc_scene *s; const float *rays; uint32_t n; float *t, *u, *v; uint32_t *prim, *nn, *nt, *occ; int mode;
+} trace_job;
+static void trace_closest_body(void *c, uint32_t b, uint32_t e, int tid) {
+    (void)tid;
+    trace_job *j = (trace_job *)c; uint32_t n = j->n; const float *r = j->rays;
+    for (uint32_t i = b; i < e; i++) {
+        float o[3] = {r[i], r[n + i], r[2 * (size_t)n + i]}, d[3] = {r[3 * (size_t)n + i], r[4 * (size_t)n + i], r[5 * (size_t)n + i]};
+        hit_t h; uint32_t cn, ct;
+        traverse(j->s, o, d, r[6 * (size_t)n + i], r[7 * (size_t)n + i], 0, &h, &cn, &ct);
+        j->t[i] = h.t; j->u[i] = h.u; j->v[i] = h.v; j->prim[i] = h.prim;
+        if (j->nn) j->nn[i] = cn;
+        if (j->nt) j->nt[i] = ct;
+    }
+}
+void orc_trace_closest(const orc_scene *s, const float *rays, uint32_t n, float *t, float *u, float *v, uint32_t *prim,
+                       uint32_t *n_nodes, uint32_t *n_tris, int n_threads) {
+    trace_job j = {s, rays, n, t, u, v, prim, n_nodes, n_tris, NULL, 0};
+    parallel_for(n, n_threads, trace_closest_body, &j);
+}
+static void trace_any_body(void *c, uint32_t b, uint32_t e, int tid) {
+    (void)tid;
+    trace_job *j = (trace_job *)c; uint32_t n = j->n; const float *r = j->rays;
+    for (uint32_t i = b; i < e; i++) {
+        float o[3] = {r[i], r[n + i], r[2 * (size_t)n + i]}, d[3] = {r[3 * (size_t)n + i], r[4 * (size_t)n + i], r[5 * (size_t)n + i]};
+        hit_t h; uint32_t cn, ct;
+        traverse(j->s, o, d, r[6 * (size_t)n + i], r[7 * (size_t)n + i], 1, &h, &cn, &ct);
+        j->occ[i] = h.prim != ORC_MISS;
+        if (j->nn) j->nn[i] = cn;
+        if (j->nt) j->nt[i] = ct;
+    }
+}
+void orc_trace_any(const orc_scene *s, const float *rays, uint32_t n, uint32_t *occluded, uint32_t *n_nodes,
+                   uint32_t *n_tris, int n_threads) {
+    trace_job j = {s, rays, n, NULL, NULL, NULL, NULL, n_nodes, n_tris, occluded, 0};
+    parallel_for(n, n_threads, trace_any_body, &j);
+}
+/* double-precision Moeller-Trumbore, used only to pin the fp32 test */
+static void tri_test_f64(const float *tr, const float of[3], const float df[3], double tmin, double *bt, double *bu, double *bv, uint32_t *bp) {
+    double v0[3], e1[3], e2[3], o[3], d[3], pv[3], tv[3], qv[3];
+    for (int k = 0; k < 3; k++) { v0[k] = tr[k]; e1[k] = tr[3 + k]; e2[k] = tr[6 + k]; o[k] = of[k]; d[k] = df[k]; }
+    pv[0] = d[1] * e2[2] - d[2] * e2[1]; pv[1] = d[2] * e2[0] - d[0] * e2[2]; pv[2] = d[0] * e2[1] - d[1] * e2[0];
+    double det = e1[0] * pv[0] + e1[1] * pv[1] + e1[2] * pv[2];
+    if (det == 0.0) return;
+    double inv = 1.0 / det;
+    for (int k = 0; k < 3; k++) tv[k] = o[k] - v0[k];
+    double u = (tv[0] * pv[0] + tv[1] * pv[1] + tv[2] * pv[2]) * inv;
+    if (!(u >= 0.0 && u <= 1.0)) return;
+    qv[0] = tv[1] * e1[2] - tv[2] * e1[1]; qv[1] = tv[2] * e1[0] - tv[0] * e1[2]; qv[2] = tv[0] * e1[1] - tv[1] * e1[0];
+    double v = (d[0] * qv[0] + d[1] * qv[1] + d[2] * qv[2]) * inv;
+    if (!(v >= 0.0 && u + v <= 1.0)) return;
+    double t = (e2[0] * qv[0] + e2[1] * qv[1] + e2[2] * qv[2]) * inv;
+    uint32_t prim = f2u(tr[9]);
+    if (t > tmin && (t < *bt || (t == *bt && prim < *bp))) { *bt = t; *bu = u; *bv = v; *bp = prim; }
+}
+static void trace_brute_body(void *c, uint32_t b, uint32_t e, int tid) {
+    (void)tid;
+    trace_job *j = (trace_job *)c; uint32_t n = j->n; const float *r = j->rays; const orc_scene *s = j->s;
+    for (uint32_t i = b; i < e; i++) {
+        float o[3] = {r[i], r[n + i], r[2 * (size_t)n + i]}, d[3] = {r[3 * (size_t)n + i], r[4 * (size_t)n + i], r[5 * (size_t)n + i]};
+        float tmin = r[6 * (size_t)n + i], tmax = r[7 * (size_t)n + i];
+        if (j->mode == 0) {
+            hit_t best = {tmax, 0.0f, 0.0f, ORC_MISS};
+            for (uint32_t k = 0; k < s->n_tris; k++) tri_test(s->tris + 12 * (size_t)k, o, d, tmin, &best);
+            j->t[i] = best.t; j->u[i] = best.u; j->v[i] = best.v; j->prim[i] = best.prim;
+        } else {
+            double bt = tmax, bu = 0, bv = 0; uint32_t bp = ORC_MISS;
+            for (uint32_t k = 0; k < s->n_tris; k++) tri_test_f64(s->tris + 12 * (size_t)k, o, d, tmin, &bt, &bu, &bv, &bp);
+            j->t[i] = (float)bt; j->u[i] = (float)bu; j->v[i] = (float)bv; j->prim[i] = bp;
+        }
+    }
+}
+void orc_trace_brute(const orc_scene *s, const float *rays, uint32_t n, float *t, float *u, float *v, uint32_t *prim,
+                     int mode, int n_threads) {
+    trace_job j = {s, rays, n, t, u, v, prim, NULL, NULL, NULL, mode};
+    parallel_for(n, n_threads, trace_brute_body, &j);
+}
+
+/* ------------------------------------------------------------------------------------------------ hit_info */
+/* hit_logic.slang:5-40 with GeometryInfo.transform := identity, Vertex.color := 1, no textures (index -1);
+ * surf = albedo[3] emissive[3] normal[3] roughness metalness */
+void orc_hit_info(const orc_scene *s, uint32_t prim, float bu, float bv, float surf[11]) {
+    uint32_t g = s->prim_geom[prim], local = prim - s->first_prim[g];
+    const orc_geometry_info *gi = &s->geoms[g];
+    uint32_t io = gi->index_offset + 3u * local;
+    const float *v0 = s->verts + 8 * (size_t)(gi->vertex_offset + s->indices[io]);
+    const float *v1 = s->verts + 8 * (size_t)(gi->vertex_offset + s->indices[io + 1]);
+    const float *v2 = s->verts + 8 * (size_t)(gi->vertex_offset + s->indices[io + 2]);
+    float b0 = 1.0f - bu - bv, b1 = bu, b2 = bv;
+    float n[3];
+    for (int k = 0; k < 3; k++) n[k] = v0[3 + k] * b0 + v1[3 + k] * b1 + v2[3 + k] * b2;
+    normalize3(n); /* :24 */
+    normalize3(n); /* :25 (identity transform, second normalize kept) */
+    surf[0] = gi->base_color[0]; surf[1] = gi->base_color[1]; surf[2] = gi->base_color[2];
+    surf[3] = gi->emission[0] * 12.0f; surf[4] = gi->emission[1] * 12.0f; surf[5] = gi->emission[2] * 12.0f; /* :36 */
+    surf[6] = n[0]; surf[7] = n[1]; surf[8] = n[2];
+    surf[9] = gi->roughness; surf[10] = gi->metallic_factor;
+}
+
+/* ------------------------------------------------------------------------------------------------ sky [north_star] */
+/* bilinear equirect lookup (Skybox.SampleLevel(uv, 0), postprocess.slang:102-104): wrap in u, clamp in v */
+static void sky_eval(const orc_scene *s, float u, float v, float out[3]) {
+    if (!s->sky) { out[0] = out[1] = out[2] = 0.0f; return; }
+    int W = (int)s->sky_w, H = (int)s->sky_h;
+    float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    float xf = floorf(x), yf = floorf(y);
+    float fx = x - xf, fy = y - yf;
+    int x0 = (int)xf, y0 = (int)yf;
+    int x1 = x0 + 1, y1 = y0 + 1;
+    x0 = ((x0 % W) + W) % W; x1 = ((x1 % W) + W) % W;
+    y0 = y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0);
+    y1 = y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1);
+    const float *p00 = s->sky + 3 * ((size_t)y0 * W + x0), *p10 = s->sky + 3 * ((size_t)y0 * W + x1);
+    const float *p01 = s->sky + 3 * ((size_t)y1 * W + x0), *p11 = s->sky + 3 * ((size_t)y1 * W + x1);
+    for (int k = 0; k < 3; k++) {
+        float top = p00[k] * (1.0f - fx) + p10[k] * fx, bot = p01[k] * (1.0f - fx) + p11[k] * fx;
+        out[k] = top * (1.0f - fy) + bot * fy;
+    }
+}
+/* solid-angle pdf of the sky sampler for equirect coordinates (u,v) */
+static float sky_pdf(const orc_scene *s, float u, float v) {
+    if (!s->sky) return 0.0f;
+    int W = (int)s->sky_w, H = (int)s->sky_h;
+    int ix = (int)(u * (float)W), iy = (int)(v * (float)H);
+    ix = ix < 0 ? 0 : (ix > W - 1 ? W - 1 : ix);
+    iy = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);
+    float st, ct;
+    orc_sincos_2pi(v * 0.5f, &st, &ct);
+    if (!(st > 0.0f)) return 0.0f;
+    return s->pdf_uv[(size_t)iy * W + ix] / (2.0f * F_PI * F_PI * st);
+}
+static uint32_t cdf_find(const float *cdf, uint32_t n, float u) { /* first index with cdf[i] > u */
+    uint32_t lo = 0, hi = n - 1;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (cdf[mid] > u) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
+static void sky_sample(const orc_scene *s, float u0, float u1, float dir[3], float rad[3], float *pdf) {
+    uint32_t W = s->sky_w, H = s->sky_h;
+    uint32_t y = cdf_find(s->cdf_marg, H, u0);
+    float lo = y > 0 ? s->cdf_marg[y - 1] : 0.0f, hi = s->cdf_marg[y];
+    float dv = hi > lo ? (u0 - lo) / (hi - lo) : 0.5f;
+    const float *row = s->cdf_cond + (size_t)y * W;
+    uint32_t x = cdf_find(row, W, u1);
+    lo = x > 0 ? row[x - 1] : 0.0f; hi = row[x];
+    float du = hi > lo ? (u1 - lo) / (hi - lo) : 0.5f;
+    float u = ((float)x + du) / (float)W, v = ((float)y + dv) / (float)H;
+    float st, ct, s2, c2;
+    orc_sincos_2pi(v * 0.5f, &st, &ct);
+    orc_sincos_2pi(u, &s2, &c2);
+    dir[0] = (-c2) * st; dir[1] = ct; dir[2] = (-s2) * st;
+    sky_eval(s, u, v, rad);
+    *pdf = st > 0.0f ? s->pdf_uv[(size_t)y * W + x] / (2.0f * F_PI * F_PI * st) : 0.0f;
+}
+/* [north_star] Cranley-Patterson shift by a blue-noise channel: frac(u + c/256) */
+static inline float bn_shift(float u, uint32_t c) {
+    float r = u + (float)c * 0.00390625f;
+    return r >= 1.0f ? r - 1.0f : r;
+}
+
+/* ------------------------------------------------------------------------------------------------ passes */
+typedef struct {
+    const orc_scene *s; const orc_gconst *g; uint32_t x0, y0, x1, y1;
+    uint32_t *gbuffer; float *depth; const uint32_t *gb_in; const float *depth_in; const float *prev; float *light;
+    const float *in; float *out; uint64_t (*counts)[4];
+} pass_job;
+
+/* gbuffer.slang:8-21 */
+static void gbuffer_body(void *c, uint32_t b, uint32_t e, int tid) {
+    (void)tid;
+    pass_job *j = (pass_job *)c;
+    uint32_t W = (uint32_t)j->g->window_size[0], rw = j->x1 - j->x0;
+    for (uint32_t i = b; i < e; i++) {
+        uint32_t px = j->x0 + i % rw, py = j->y0 + i / rw;
+        float o[3], d[3];
+        orc_primary_ray(j->g, px, py, o, d);
+        hit_t h;
+        traverse(j->s, o, d, 0.0f, ORC_BACKGROUND_DEPTH, 0, &h, NULL, NULL); /* setupPrimaryRay: TMin 0, TMax 1e5 */
+        size_t pi = (size_t)py * W + px;
+        if (h.prim == ORC_MISS) {
+            j->depth[pi] = ORC_BACKGROUND_DEPTH;
+        } else {
+            float surf[11];
+            orc_hit_info(j->s, h.prim, h.u, h.v, surf);
+            orc_gbuffer_pack(surf, j->gbuffer + 4 * pi);
+            j->depth[pi] = h.t;
+        }
+    }
+}
+void orc_pass_gbuffer(const orc_scene *s, const orc_gconst *g, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
+                      uint32_t *gbuffer, float *depth, int n_threads) {
+    pass_job j; memset(&j, 0, sizeof(j));
+    j.s = s; j.g = g; j.x0 = x0; j.y0 = y0; j.x1 = x1; j.y1 = y1; j.gbuffer = gbuffer; j.depth = depth;
+    parallel_for((x1 - x0) * (y1 - y0), n_threads, gbuffer_body, &j);
+}
+
+/* refrence_mode.slang:14-66.  Deviations (all documented in DESIGN.md):
+ *  - RNG counter for (sample s, bounce b, dim d) = (s*B + b)*DIMS + d with DIMS = 2 (reference semantics) or 8
+ *    (any feature flag set) instead of the sequential `index++`;
+ *  - per-sample radiance L_s is summed over bounces first, then radiance = sum_s L_s in order;
+ *  - hit_info is not evaluated on a miss (Appendix A (4));
+ *  - [north_star] sky NEE with balance-heuristic MIS, blue-noise shift, face-forward normals behind flags. */
+static void refmode_body(void *c, uint32_t bgn, uint32_t end, int tid) {
+    pass_job *j = (pass_job *)c;
+    const orc_scene *s = j->s; const orc_gconst *g = j->g;
+    uint32_t W = (uint32_t)g->window_size[0], rw = j->x1 - j->x0;
+    const uint32_t flags = g->pad[0], B = g->bounces, S = g->samples;
+    const uint32_t dims = flags ? 8u : 2u;
+    const int nee = (flags & ORC_F_NEE_SKY) && s->sky, bnz = (flags & ORC_F_BLUENOISE) && s->bn;
+    uint64_t n_ext = 0, n_sh = 0, n_nodes = 0, n_tris = 0;
+    for (uint32_t i = bgn; i < end; i++) {
+        uint32_t px = j->x0 + i % rw, py = j->y0 + i / rw;
+        size_t pi = (size_t)py * W + px;
+        float d0 = j->depth_in[pi];
+        if (d0 == ORC_BACKGROUND_DEPTH) continue; /* :18-21 Light untouched */
+        float surf0[11];
+        orc_gbuffer_unpack(j->gb_in + 4 * pi, surf0); /* :23 */
+        uint32_t seed = orc_rng_seed(px, py, g->frame); /* :25 */
+        uint32_t bn[4] = {0, 0, 0, 0};
+        if (bnz) { const uint8_t *p = s->bn + 4 * ((size_t)(py % s->bn_h) * s->bn_w + (px % s->bn_w)); bn[0] = p[0]; bn[1] = p[1]; bn[2] = p[2]; bn[3] = p[3]; }
+        float radiance[3] = {0.0f, 0.0f, 0.0f};
+        for (uint32_t sm = 0; sm < S; sm++) { /* :28 */
+            float T[3] = {1.0f, 1.0f, 1.0f}, L[3] = {0.0f, 0.0f, 0.0f};
+            float o[3], d[3], surf[11];
+            orc_primary_ray(g, px, py, o, d); /* :30 */
+            memcpy(surf, surf0, sizeof(surf));
+            float t = d0; int hit = 1;
+            float pdf_b = 0.0f;
+            for (uint32_t b = 0; b < B; b++) { /* :36 */
+                if (!hit) { /* :37-40 (sky term commented out in the reference; [north_star] MIS-weighted sky) */
+                    if (nee) {
+                        float uv[2], rad[3];
+                        orc_dir_to_equirect_uv(d, uv);
+                        sky_eval(s, uv[0], uv[1], rad);
+                        float pl = sky_pdf(s, uv[0], uv[1]);
+                        float w = pdf_b / (pdf_b + pl);
+                        if (pdf_b > 0.0f) for (int k = 0; k < 3; k++) L[k] += T[k] * (rad[k] * w);
+                    }
+                    break;
+                }
+                uint32_t base = (sm * B + b) * dims;
+                float u0 = orc_uniform_float(seed, base), u1 = orc_uniform_float(seed, base + 1); /* :43 */
+                if (bnz) { u0 = bn_shift(u0, bn[0]); u1 = bn_shift(u1, bn[1]); }
+                float *alb = surf, *emi = surf + 3, N[3] = {surf[6], surf[7], surf[8]};
+                if ((flags & ORC_F_FACEFORWARD) && dot3(N, d) > 0.0f) { N[0] = -N[0]; N[1] = -N[1]; N[2] = -N[2]; }
+                float b1[3], b2[3], wi[3];
+                orc_onb(N, b1, b2);          /* :44 */
+                orc_diffuse_sample(u0, u1, wi); /* :45 */
+                for (int k = 0; k < 3; k++) o[k] = o[k] + t * d[k]; /* :47 */
+                for (int k = 0; k < 3; k++) L[k] += T[k] * emi[k]; /* :50 */
+                if (nee) { /* [north_star] next-event estimation against the sky */
+                    float ul0 = orc_uniform_float(seed, base + 3), ul1 = orc_uniform_float(seed, base + 4);
+                    if (bnz) { ul0 = bn_shift(ul0, bn[2]); ul1 = bn_shift(ul1, bn[3]); }
+                    float wl[3], rad[3], pl;
+                    sky_sample(s, ul0, ul1, wl, rad, &pl);
+                    float cosl = dot3(N, wl);
+                    if (cosl > 0.0f && pl > 0.0f) {
+                        float pb = cosl * F_FRAC_1_PI;
+                        float scale = (b == B - 1) ? (cosl * F_FRAC_1_PI) / pl : (cosl * F_FRAC_1_PI) / (pl + pb);
+                        hit_t sh;
+                        uint32_t cn, ct;
+                        traverse(s, o, wl, 0.001f, ORC_BACKGROUND_DEPTH, 1, &sh, &cn, &ct);
+                        n_sh++; n_nodes += cn; n_tris += ct;
+                        if (sh.prim == ORC_MISS) for (int k = 0; k < 3; k++) L[k] += (T[k] * alb[k]) * (rad[k] * scale);
+                    }
+                }
+                float nd[3];
+                onb_apply(b1, b2, N, wi, nd); /* :48 */
+                pdf_b = wi[2] * F_FRAC_1_PI;
+                for (int k = 0; k < 3; k++) { T[k] = T[k] * alb[k]; d[k] = nd[k]; } /* :51 value_over_pdf = albedo */
+                if (b != B - 1) { /* :53-56 */
+                    hit_t h; uint32_t cn, ct;
+                    traverse(s, o, d, 0.001f, ORC_BACKGROUND_DEPTH, 0, &h, &cn, &ct); /* TMin 0.001 (:31) */
+                    n_ext++; n_nodes += cn; n_tris += ct;
+                    if (h.prim == ORC_MISS) hit = 0;
+                    else { t = h.t; orc_hit_info(s, h.prim, h.u, h.v, surf); }
+                }
+            }
+            for (int k = 0; k < 3; k++) radiance[k] += L[k];
+        }
+        for (int k = 0; k < 3; k++) radiance[k] = radiance[k] / (float)S; /* :59 */
+        float *out = j->light + 4 * pi;
+        if (g->blendfactor >= 1.0f) { /* :61-65 */
+            out[0] = radiance[0]; out[1] = radiance[1]; out[2] = radiance[2]; out[3] = 0.0f;
+        } else {
+            const float *pv = j->prev + 4 * pi; float bf = g->blendfactor;
+            for (int k = 0; k < 3; k++) out[k] = pv[k] + (radiance[k] - pv[k]) * bf; /* lerp(a,b,t) = a + (b-a)*t */
+            out[3] = 0.0f;
+        }
+    }
+    if (j->counts) { j->counts[tid][0] = n_ext; j->counts[tid][1] = n_sh; j->counts[tid][2] = n_nodes; j->counts[tid][3] = n_tris; }
+}
+void orc_pass_reference_mode(const orc_scene *s, const orc_gconst *g, uint32_t x0, uint32_t y0, uint32_t x1,
+                             uint32_t y1, const uint32_t *gbuffer, const float *depth, const float *prev_light,
+                             float *light, uint64_t *ray_counts, int n_threads) {
+    pass_job j; memset(&j, 0, sizeof(j));
+    uint64_t counts[256][4]; memset(counts, 0, sizeof(counts));
+    j.s = s; j.g = g; j.x0 = x0; j.y0 = y0; j.x1 = x1; j.y1 = y1; j.gb_in = gbuffer; j.depth_in = depth;
+    j.prev = prev_light; j.light = light; j.counts = counts;
+    parallel_for((x1 - x0) * (y1 - y0), n_threads, refmode_body, &j);
+    if (ray_counts) {
+        for (int k = 0; k < 4; k++) ray_counts[k] = 0;
+        for (int t = 0; t < 256; t++) for (int k = 0; k < 4; k++) ray_counts[k] += counts[t][k];
+    }
+}
+/* postprocess.slang:90-112 */
+static void post_body(void *c, uint32_t b, uint32_t e, int tid) {
+    (void)tid;
+    pass_job *j = (pass_job *)c;
+    uint32_t W = (uint32_t)j->g->window_size[0], rw = j->x1 - j->x0;
+    for (uint32_t i = b; i < e; i++) {
+        uint32_t px = j->x0 + i % rw, py = j->y0 + i / rw;
+        size_t pi = (size_t)py * W + px;
+        float col[3], outc[3];
+        if (j->depth_in[pi] != ORC_BACKGROUND_DEPTH) {
+            col[0] = j->in[4 * pi]; col[1] = j->in[4 * pi + 1]; col[2] = j->in[4 * pi + 2];
+        } else {
+            float o[3], d[3], uv[2];
+            orc_primary_ray(j->g, px, py, o, d);
+            orc_dir_to_equirect_uv(d, uv);
+            sky_eval(j->s, uv[0], uv[1], col);
+        }
+        orc_agx_tonemap(col, outc);
+        j->out[4 * pi] = outc[0]; j->out[4 * pi + 1] = outc[1]; j->out[4 * pi + 2] = outc[2]; j->out[4 * pi + 3] = 1.0f;
+    }
+}
+void orc_pass_postprocess(const orc_scene *s, const orc_gconst *g, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
+                          const float *depth, const float *in, float *out, int n_threads) {
+    pass_job j; memset(&j, 0, sizeof(j));
+    j.s = s; j.g = g; j.x0 = x0; j.y0 = y0; j.x1 = x1; j.y1 = y1; j.depth_in = depth; j.in = in; j.out = out;
+    parallel_for((x1 - x0) * (y1 - y0), n_threads, post_body, &j);
+}
+
+/* ------------------------------------------------------------------------------------------------ tiles [north_star] */
+static uint32_t compact1by1(uint32_t x) {
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu;
+    x = (x | (x >> 8)) & 0x0000FFFFu;
+    return x;
+}
+uint32_t orc_tile_pixels(uint32_t w, uint32_t h, uint32_t rank, uint32_t n_ranks, uint32_t *out_xy) {
+    uint32_t tw = (w + 63) / 64, th = (h + 63) / 64, count = 0, tile_no = 0;
+    uint32_t side = 1;
+    while (side < tw || side < th) side *= 2;
+    for (uint32_t z = 0; z < side * side; z++) {
+        uint32_t tx = compact1by1(z), ty = compact1by1(z >> 1);
+        if (tx >= tw || ty >= th) continue;
+        uint32_t owner = tile_no % n_ranks;
+        tile_no++;
+        if (owner != rank) continue;
+        for (uint32_t k = 0; k < 4096; k++) {
+            uint32_t x = tx * 64 + compact1by1(k), y = ty * 64 + compact1by1(k >> 1);
+            if (x >= w || y >= h) continue;
+            if (out_xy) { out_xy[2 * count] = x; out_xy[2 * count + 1] = y; }
+            count++;
+        }
+    }
+    return count;
+}

@@ -1,0 +1,200 @@
+"""ctypes binding of the CPU oracle (oracle/librt3_oracle.so).  TEST INFRASTRUCTURE ONLY -- the product never imports this."""
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+_lib = None
+
+MISS = 0xFFFFFFFF
+BACKGROUND_DEPTH = 100000.0
+F_NEE_SKY, F_BLUENOISE, F_SPECULAR, F_FACEFORWARD = 1, 2, 4, 8
+
+
+class GConst(C.Structure):
+    _fields_ = [("proj", C.c_float * 16), ("view", C.c_float * 16), ("proj_inverse", C.c_float * 16), ("view_inverse", C.c_float * 16),
+                ("window_size", C.c_float * 2), ("frame", C.c_uint32), ("blendfactor", C.c_float), ("bounces", C.c_uint32),
+                ("samples", C.c_uint32), ("proberng", C.c_uint32), ("cell_size", C.c_float), ("mouse", C.c_uint32 * 2), ("pad", C.c_uint32 * 2)]
+
+
+assert C.sizeof(GConst) == 304
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(str(ROOT / "oracle" / "librt3_oracle.so"))
+        L = _lib
+        u32, f32, vp = C.c_uint32, C.c_float, C.c_void_p
+        L.orc_hash.restype = u32; L.orc_hash.argtypes = [u32]
+        L.orc_zcurve.restype = u32; L.orc_zcurve.argtypes = [u32, u32]
+        L.orc_rng_seed.restype = u32; L.orc_rng_seed.argtypes = [u32, u32, u32]
+        L.orc_murmur3.restype = u32; L.orc_murmur3.argtypes = [u32, u32]
+        L.orc_uniform_float.restype = f32; L.orc_uniform_float.argtypes = [u32, u32]
+        L.orc_radical_inverse_bits.restype = u32; L.orc_radical_inverse_bits.argtypes = [u32]
+        L.orc_pack_color_888.restype = u32; L.orc_pack_normal_11_10_11.restype = u32
+        L.orc_pack_2x16f.restype = u32; L.orc_pack_2x16f.argtypes = [f32, f32]
+        L.orc_float3_to_rgb9e5.restype = u32
+        L.orc_atan2.restype = f32; L.orc_atan2.argtypes = [f32, f32]
+        L.orc_sincos_2pi.argtypes = [f32, vp, vp]
+        L.orc_diffuse_sample.argtypes = [f32, f32, vp]
+        L.orc_camera_gconst.argtypes = [vp, vp, f32, f32, f32, f32, f32, f32, vp]
+        L.orc_primary_ray.argtypes = [vp, u32, u32, vp, vp]
+        L.orc_scene_create.restype = vp
+        for n in ("orc_scene_destroy", "orc_accel_build"):
+            getattr(L, n).argtypes = [vp]
+        L.orc_scene_set_vertices.argtypes = [vp, vp, u32]
+        L.orc_scene_set_indices.argtypes = [vp, vp, u32]
+        L.orc_scene_set_geometry.argtypes = [vp, vp, vp, u32]
+        L.orc_scene_set_sky.argtypes = [vp, vp, u32, u32]
+        L.orc_scene_set_bluenoise.argtypes = [vp, vp, u32, u32]
+        for n in ("orc_accel_num_tris", "orc_accel_num_nodes", "orc_accel_max_depth"):
+            getattr(L, n).restype = u32; getattr(L, n).argtypes = [vp]
+        for n in ("orc_accel_nodes", "orc_accel_tris", "orc_accel_codes", "orc_sky_cdf_cond", "orc_sky_cdf_marg", "orc_sky_pdf_uv"):
+            getattr(L, n).restype = vp; getattr(L, n).argtypes = [vp]
+        L.orc_trace_closest.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp, C.c_int]
+        L.orc_trace_any.argtypes = [vp, vp, u32, vp, vp, vp, C.c_int]
+        L.orc_trace_brute.argtypes = [vp, vp, u32, vp, vp, vp, vp, C.c_int, C.c_int]
+        L.orc_hit_info.argtypes = [vp, u32, f32, f32, vp]
+        L.orc_pass_gbuffer.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, C.c_int]
+        L.orc_pass_reference_mode.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, vp, vp, vp, C.c_int]
+        L.orc_pass_postprocess.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, vp, C.c_int]
+        L.orc_tile_pixels.restype = u32; L.orc_tile_pixels.argtypes = [u32, u32, u32, u32, vp]
+    return _lib
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def f3(x):
+    return (C.c_float * 3)(*[float(v) for v in x])
+
+
+def camera_gconst(position, direction, fov_deg, width, height, z_near=0.1, z_far=1000.0, aspect=None):
+    g = GConst()
+    asp = (width / height) if aspect is None else aspect
+    lib().orc_camera_gconst(f3(position), f3(direction), float(np.float32(np.deg2rad(np.float32(fov_deg)))), float(np.float32(asp)),
+                            z_near, z_far, float(width), float(height), C.byref(g))
+    return g
+
+
+class Scene:
+    def __init__(self, mesh, sky=None, bluenoise=None, build=True):
+        L = lib()
+        self.h = L.orc_scene_create()
+        self.mesh = mesh
+        v = np.ascontiguousarray(mesh.vertices, np.float32); i = np.ascontiguousarray(mesh.indices, np.uint32)
+        L.orc_scene_set_vertices(self.h, ptr(v), len(v))
+        L.orc_scene_set_indices(self.h, ptr(i), len(i))
+        g = np.ascontiguousarray(mesh.geometries); pc = np.ascontiguousarray(mesh.prim_counts, np.uint32)
+        L.orc_scene_set_geometry(self.h, ptr(g), ptr(pc), len(g))
+        if sky is not None:
+            s = np.ascontiguousarray(sky, np.float32)
+            L.orc_scene_set_sky(self.h, ptr(s), s.shape[1], s.shape[0])
+        if bluenoise is not None:
+            b = np.ascontiguousarray(bluenoise, np.uint8)
+            L.orc_scene_set_bluenoise(self.h, ptr(b), b.shape[1], b.shape[0])
+        if build:
+            L.orc_accel_build(self.h)
+
+    def __del__(self):
+        try:
+            lib().orc_scene_destroy(self.h)
+        except Exception:
+            pass
+
+    @property
+    def n_tris(self):
+        return lib().orc_accel_num_tris(self.h)
+
+    @property
+    def n_nodes(self):
+        return lib().orc_accel_num_nodes(self.h)
+
+    @property
+    def max_depth(self):
+        return lib().orc_accel_max_depth(self.h)
+
+    def nodes(self):
+        n = self.n_nodes
+        return np.ctypeslib.as_array(C.cast(lib().orc_accel_nodes(self.h), C.POINTER(C.c_uint32)), (n, 16)).copy()
+
+    def tris(self):
+        n = self.n_tris
+        return np.ctypeslib.as_array(C.cast(lib().orc_accel_tris(self.h), C.POINTER(C.c_uint32)), (n, 12)).copy()
+
+    def codes(self):
+        n = self.n_tris
+        return np.ctypeslib.as_array(C.cast(lib().orc_accel_codes(self.h), C.POINTER(C.c_uint64)), (n,)).copy()
+
+    def sky_tables(self, w, h):
+        L = lib()
+        cc = np.ctypeslib.as_array(C.cast(L.orc_sky_cdf_cond(self.h), C.POINTER(C.c_float)), (h, w)).copy()
+        cm = np.ctypeslib.as_array(C.cast(L.orc_sky_cdf_marg(self.h), C.POINTER(C.c_float)), (h,)).copy()
+        pu = np.ctypeslib.as_array(C.cast(L.orc_sky_pdf_uv(self.h), C.POINTER(C.c_float)), (h, w)).copy()
+        return cc, cm, pu
+
+    def trace_closest(self, rays, threads=8, counts=False):
+        """rays: (8, n) float32 SoA ox,oy,oz,dx,dy,dz,tmin,tmax"""
+        rays = np.ascontiguousarray(rays, np.float32); n = rays.shape[1]
+        t = np.empty(n, np.float32); u = np.empty(n, np.float32); v = np.empty(n, np.float32); p = np.empty(n, np.uint32)
+        nn = np.empty(n, np.uint32) if counts else None; nt = np.empty(n, np.uint32) if counts else None
+        lib().orc_trace_closest(self.h, ptr(rays), n, ptr(t), ptr(u), ptr(v), ptr(p), ptr(nn), ptr(nt), threads)
+        return (t, u, v, p, nn, nt) if counts else (t, u, v, p)
+
+    def trace_any(self, rays, threads=8, counts=False):
+        rays = np.ascontiguousarray(rays, np.float32); n = rays.shape[1]
+        occ = np.empty(n, np.uint32)
+        nn = np.empty(n, np.uint32) if counts else None; nt = np.empty(n, np.uint32) if counts else None
+        lib().orc_trace_any(self.h, ptr(rays), n, ptr(occ), ptr(nn), ptr(nt), threads)
+        return (occ, nn, nt) if counts else occ
+
+    def trace_brute(self, rays, mode=0, threads=8):
+        rays = np.ascontiguousarray(rays, np.float32); n = rays.shape[1]
+        t = np.empty(n, np.float32); u = np.empty(n, np.float32); v = np.empty(n, np.float32); p = np.empty(n, np.uint32)
+        lib().orc_trace_brute(self.h, ptr(rays), n, ptr(t), ptr(u), ptr(v), ptr(p), mode, threads)
+        return t, u, v, p
+
+    def gbuffer(self, g, rect=None, threads=8):
+        W, H = int(g.window_size[0]), int(g.window_size[1])
+        x0, y0, x1, y1 = rect or (0, 0, W, H)
+        gb = np.zeros((H, W, 4), np.uint32); depth = np.zeros((H, W), np.float32)
+        lib().orc_pass_gbuffer(self.h, C.byref(g), x0, y0, x1, y1, ptr(gb), ptr(depth), threads)
+        return gb, depth
+
+    def reference_mode(self, g, gb, depth, prev=None, rect=None, threads=8):
+        W, H = int(g.window_size[0]), int(g.window_size[1])
+        x0, y0, x1, y1 = rect or (0, 0, W, H)
+        light = np.zeros((H, W, 4), np.float32) if prev is None else prev.copy()
+        prev = np.zeros((H, W, 4), np.float32) if prev is None else np.ascontiguousarray(prev, np.float32)
+        counts = np.zeros(4, np.uint64)
+        lib().orc_pass_reference_mode(self.h, C.byref(g), x0, y0, x1, y1, ptr(gb), ptr(depth), ptr(prev), ptr(light), ptr(counts), threads)
+        return light, counts
+
+    def postprocess(self, g, depth, img, rect=None, threads=8):
+        W, H = int(g.window_size[0]), int(g.window_size[1])
+        x0, y0, x1, y1 = rect or (0, 0, W, H)
+        out = np.zeros((H, W, 4), np.float32)
+        lib().orc_pass_postprocess(self.h, C.byref(g), x0, y0, x1, y1, ptr(depth), ptr(np.ascontiguousarray(img, np.float32)), ptr(out), threads)
+        return out
+
+
+def primary_rays(g, xs, ys, tmin=0.0, tmax=BACKGROUND_DEPTH):
+    n = len(xs)
+    rays = np.empty((8, n), np.float32)
+    o = (C.c_float * 3)(); d = (C.c_float * 3)()
+    L = lib()
+    for i, (x, y) in enumerate(zip(xs, ys)):
+        L.orc_primary_ray(C.byref(g), int(x), int(y), o, d)
+        rays[0:3, i] = o[:]; rays[3:6, i] = d[:]
+    rays[6] = tmin; rays[7] = tmax
+    return rays
+
+
+def tile_pixels(w, h, rank, n_ranks):
+    n = lib().orc_tile_pixels(w, h, rank, n_ranks, None)
+    out = np.empty((n, 2), np.uint32)
+    lib().orc_tile_pixels(w, h, rank, n_ranks, ptr(out))
+    return out

@@ -1,0 +1,122 @@
+"""Known-answer tests pinning the oracle's integer functions (the reference has no tests; these values
+were derived at survey time by an independent restatement of random.slang:5-15,49-89 and math.slang:105-117)."""
+import ctypes as C
+
+import numpy as np
+
+import orc
+
+
+def test_hash_kat():
+    L = orc.lib()
+    assert L.orc_hash(0) == 0x6B4ED927
+    assert L.orc_hash(1) == 0xB48681B6
+    assert L.orc_hash(0xDEADBEEF) == 0x7FF0EADA
+
+
+def test_zcurve_kat():
+    L = orc.lib()
+    assert L.orc_zcurve(3, 5) == 39
+    assert L.orc_zcurve(1919, 1079) == 3481471
+    assert L.orc_zcurve(65535, 65535) == 0xFFFFFFFF
+
+
+def test_rng_kat():
+    L = orc.lib()
+    s = L.orc_rng_seed(0, 0, 0)
+    assert s == 0x6B4ED927
+    assert [L.orc_murmur3(s, i) for i in range(3)] == [0x312DDF77, 0xE5DEE3C0, 0x2276F4DC]
+    fl = [L.orc_uniform_float(s, i) for i in range(3)]
+    assert fl == [0.35838210582733154, 0.7413253784179688, 0.9293475151062012]
+    s = L.orc_rng_seed(1, 0, 0)
+    assert s == 0xB48681B6
+    assert [L.orc_murmur3(s, i) for i in range(3)] == [0xB16DAF3E, 0x5D8C2647, 0xFE2AEDF2]
+    s = L.orc_rng_seed(960, 540, 7)
+    assert s == 0xEE26C3FF
+    assert [L.orc_murmur3(s, i) for i in range(3)] == [0x5006FA9B, 0xFC20C6EE, 0x81C9C292]
+
+
+def test_radical_inverse_kat():
+    L = orc.lib()
+    assert [L.orc_radical_inverse_bits(i) for i in (1, 2, 3)] == [0x80000000, 0x40000000, 0xC0000000]
+
+
+def test_murmur3_matches_independent_python():
+    def mm(seed, k):
+        M = 0xFFFFFFFF
+        k = (k * 0xCC9E2D51) & M; k = ((k << 15) | (k >> 17)) & M; k = (k * 0x1B873593) & M
+        h = seed ^ k; h = ((h << 13) | (h >> 19)) & M; h = (h * 5 + 0xE6546B64) & M
+        h ^= 4; h ^= h >> 16; h = (h * 0x85EBCA6B) & M; h ^= h >> 13; h = (h * 0xC2B2AE35) & M; h ^= h >> 16
+        return h
+    L = orc.lib()
+    rng = np.random.default_rng(1)
+    for seed, k in rng.integers(0, 2**32, size=(200, 2), dtype=np.uint64):
+        assert L.orc_murmur3(int(seed), int(k)) == mm(int(seed), int(k))
+
+
+def test_f16_matches_numpy():
+    L = orc.lib()
+    rng = np.random.default_rng(2)
+    vals = np.concatenate([rng.uniform(-70000, 70000, 2000), rng.uniform(-1e-4, 1e-4, 2000), rng.uniform(-1, 1, 2000),
+                           [0.0, 1.0, 65504.0, 65519.9, 65520.0, 6e-8, 5.96e-8, 2.98e-8, 2.9802322e-8, 1e-9]]).astype(np.float32)
+    out = (C.c_float * 2)()
+    for v in vals:
+        p = L.orc_pack_2x16f(float(v), 0.0)
+        h = np.array([v], np.float32).astype(np.float16)
+        assert (p & 0xFFFF) == int(h.view(np.uint16)[0]), v
+        L.orc_unpack_2x16f(p, out)
+        exp = float(h.astype(np.float32)[0])
+        assert out[0] == exp or (np.isinf(exp) and np.isinf(out[0]))
+
+
+def test_pack_roundtrips():
+    L = orc.lib()
+    rng = np.random.default_rng(3)
+    for _ in range(64):
+        c = rng.uniform(0, 1, 3).astype(np.float32)
+        p = L.orc_pack_color_888(orc.f3(c))
+        o = (C.c_float * 3)(); L.orc_unpack_color_888(p, o)
+        assert np.allclose(np.sqrt(np.array(o[:])), np.sqrt(c), atol=0.5 / 255 + 1e-6)
+        n = rng.normal(size=3); n = (n / np.linalg.norm(n)).astype(np.float32)
+        p = L.orc_pack_normal_11_10_11(orc.f3(n)); L.orc_unpack_normal_11_10_11(p, o)
+        assert np.dot(np.array(o[:]), n) > 0.99999 - 2e-6 * 1023
+        e = (rng.uniform(0, 1, 3) * 10 ** rng.uniform(-3, 3)).astype(np.float32)
+        p = L.orc_float3_to_rgb9e5(orc.f3(e)); L.orc_rgb9e5_to_float3(p, o)
+        assert np.allclose(np.array(o[:]), e, atol=float(e.max()) / 256)
+    # rgb9e5 KATs computed by hand from the EXT_texture_shared_exponent rules: (1,1,1) -> mantissa 256, exp 16
+    assert L.orc_float3_to_rgb9e5(orc.f3((1, 1, 1))) == (256 << 23) | (256 << 14) | (256 << 5) | 16
+    assert L.orc_float3_to_rgb9e5(orc.f3((0, 0, 0))) == 0
+    assert L.orc_float3_to_rgb9e5(orc.f3((12, 6, 3))) == (384 << 23) | (192 << 14) | (96 << 5) | 19
+
+
+def test_sincos_atan_accuracy():
+    L = orc.lib()
+    s = C.c_float(); c = C.c_float()
+    for u in np.linspace(0, 1, 4001, endpoint=False, dtype=np.float32):
+        L.orc_sincos_2pi(float(u), C.byref(s), C.byref(c))
+        assert abs(s.value - np.sin(2 * np.pi * float(u))) < 3e-7
+        assert abs(c.value - np.cos(2 * np.pi * float(u))) < 3e-7
+    rng = np.random.default_rng(4)
+    for y, x in rng.normal(size=(2000, 2)).astype(np.float32):
+        assert abs(L.orc_atan2(float(y), float(x)) - np.arctan2(float(y), float(x))) < 2e-5
+
+
+def test_camera_default_matrices():
+    """camera.rs:52-58 / main.rs:69-76 defaults: position (0,0,-1) looking +z, fov 65 deg, 1920x1088, 0.1..1000."""
+    g = orc.camera_gconst((0, 0, -1), (0, 0, 1), 65.0, 1920, 1088)
+    view = np.array(g.view[:], np.float64).reshape(4, 4).T
+    proj = np.array(g.proj[:], np.float64).reshape(4, 4).T
+    # look_at_rh: s = f x up = (0,0,1)x(0,1,0) = (-1,0,0); u = s x f = (0,1,0); view maps +z world to -z view
+    exp_view = np.array([[-1, 0, 0, 0], [0, 1, 0, 0], [0, 0, -1, -1], [0, 0, 0, 1]], np.float64)
+    assert np.allclose(view, exp_view, atol=1e-7)
+    h = 1 / np.tan(np.deg2rad(65.0) / 2)
+    assert np.isclose(proj[1, 1], h, rtol=1e-6) and np.isclose(proj[0, 0], h / (1920 / 1088), rtol=1e-6)
+    assert np.isclose(proj[2, 2], 1000 / (0.1 - 1000), rtol=1e-6) and proj[3, 2] == -1 and np.isclose(proj[2, 3], 0.1 * 1000 / (0.1 - 1000), rtol=1e-6)
+    assert np.allclose(np.array(g.proj_inverse[:]).reshape(4, 4).T @ proj, np.eye(4), atol=1e-5)
+    assert np.allclose(np.array(g.view_inverse[:]).reshape(4, 4).T @ view, np.eye(4), atol=1e-6)
+    # centre pixel looks along +z, top-left pixel looks up-and-(-x view = +x world?) : check upright image (y flip)
+    r = orc.primary_rays(g, [960, 0], [544, 0])
+    assert np.allclose(r[0:3, 0], (0, 0, -1))
+    assert r[5, 0] > 0.999
+    assert r[4, 1] > 0  # top row looks up
+    assert r[3, 1] > 0  # left column: view -x == world +x for a camera looking down +z in a right-handed frame
