@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path (BASELINE.json: "Mrays/s + ms/frame, Sponza 1080p@64spp").
+
+A step = one frame: gbuffer pass + refrence_mode pass (B = 4, full estimator: diffuse BSDF + sky NEE/MIS +
+blue-noise shift) over this rank's 64x64 tiles, then ONE gather of the per-rank tile buffers to rank 0.
+Workload = configs[2] (C3): atrium stand-in (sponza_scene.glb is not shipped), 1920x1080 @ 64 spp.
+value = Mrays/s = (primary + bounce + shadow rays of all ranks) / max-over-ranks frame time; ms_per_step = ms/frame.
+Strong scaling: the frame is fixed, tiles are split over the ranks.
+
+Extra objects on the JSON line:
+  roofline     k_extend: algorithmic bytes (48 + 64 n_nodes + 48 n_tris per ray) / HIP-event time
+               of the k_extend launches inside the timed region, against the 8 TB/s HBM3E peak
+  cpu_baseline the CPU oracle (a port; the reference cannot be built here) path tracing a centred crop of the same
+               frame on the host cores; the crop also yields rmse_vs_oracle
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spp", type=int, default=64)
+    ap.add_argument("--bounces", type=int, default=4)
+    ap.add_argument("--detail", type=float, default=1.0)
+    ap.add_argument("--batch-spp", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-crop", type=str, default="320x180")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+
+    from raytracer3_amd import _lib as L
+    from raytracer3_amd import assets, scenes
+    from raytracer3_amd.renderer import DEFAULT_FLAGS, Camera, PathTracer
+
+    W, H = args.width, args.height
+    mesh = scenes.atrium(args.detail)
+    sky = scenes.sky(2048, 1024)
+    bn = assets.load_bluenoise()
+    pt = PathTracer((W, H), device=local_rank, rank=rank, n_ranks=world)
+    pt.set_scene(mesh, sky, bn)
+    if args.batch_spp:
+        pt.ctx.set_option(L.OPT_BATCH_SPP, args.batch_spp)
+    cam = Camera(scenes.ATRIUM_CAMERA["position"], scenes.ATRIUM_CAMERA["direction"], math.radians(scenes.ATRIUM_CAMERA["fov_deg"]), W / H)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        pt.ctx.wait()
+        torch.cuda.synchronize()
+
+    def frame(i):
+        g = pt.make_gconst(cam, args.spp, args.bounces, frame=i, flags=DEFAULT_FLAGS)
+        pt.render(g, postprocess=False, wait=False)
+        return pt.gather_light(dist, torch) if world > 1 else None, g
+
+    for i in range(args.warmup):
+        frame(i)
+    pt.ctx.set_option(L.OPT_PROFILE, 1)  # HIP events around every kernel, on the context's own stream
+    barrier()
+    pt.ctx.stats_reset()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        _, g_last = frame(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    st = pt.ctx.stats()
+    pt.ctx.set_option(L.OPT_PROFILE, 0)
+
+    rays_local = st.extension_rays + st.shadow_rays
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        rr = torch.tensor([float(rays_local), float(st.extension_rays), float(st.shadow_rays)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+        dt = float(tt.item())
+        rays_total, ext_total, sh_total = (float(x) for x in rr.tolist())
+    else:
+        rays_total, ext_total, sh_total = float(rays_local), float(st.extension_rays), float(st.shadow_rays)
+
+    # ---- roofline of the dominant kernel (k_extend) on this rank: one untimed counting frame gives n_nodes / n_tris
+    pt.ctx.set_option(L.OPT_COUNT_TRAVERSAL, 1)
+    pt.ctx.stats_reset()
+    pt.render(g_last, postprocess=False, wait=True)
+    cst = pt.ctx.stats()
+    pt.ctx.set_option(L.OPT_COUNT_TRAVERSAL, 0)
+    bytes_per_frame = 48.0 * cst.extension_rays + 64.0 * cst.nodes_visited + 48.0 * cst.tris_tested
+    sh_bytes_per_frame = 48.0 * cst.shadow_rays + 64.0 * cst.shadow_nodes_visited + 48.0 * cst.shadow_tris_tested
+    ext_ms_per_frame = st.extend_ms / max(args.steps, 1)
+    launches_per_frame = st.extend_launches / max(args.steps, 1)
+    achieved = bytes_per_frame / (ext_ms_per_frame * 1e-3) / 1e9 if ext_ms_per_frame > 0 else 0.0
+    peak = 8000.0
+    roofline = {
+        "kernel": "k_extend", "bound": "hbm", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s", "frac": round(achieved / peak, 4),
+        "traffic": None,  # HBM bytes from rocprofv3 PMC passes: see profiles/ and DESIGN.md (not collectable inside bench.py)
+        "launches_per_frame": launches_per_frame, "avg_launch_ms": round(ext_ms_per_frame / max(launches_per_frame, 1), 4),
+        "algorithmic_bytes_per_launch": round(bytes_per_frame / max(launches_per_frame, 1)),
+        "rays_per_frame": int(cst.extension_rays), "nodes_per_ray": round(cst.nodes_visited / max(cst.extension_rays, 1), 2),
+        "tris_per_ray": round(cst.tris_tested / max(cst.extension_rays, 1), 2),
+        "k_shadow": {"achieved": round(sh_bytes_per_frame / max(st.shadow_ms / max(args.steps, 1) * 1e-3, 1e-12) / 1e9, 1),
+                     "rays_per_frame": int(cst.shadow_rays), "ms_per_frame": round(st.shadow_ms / max(args.steps, 1), 3)},
+        "ms_per_frame": {"k_extend": round(ext_ms_per_frame, 3), "k_shadow": round(st.shadow_ms / max(args.steps, 1), 3),
+                         "k_shade": round(st.shade_ms / max(args.steps, 1), 3), "other": round(st.other_ms / max(args.steps, 1), 3)},
+    }
+
+    out = {
+        "metric": "Mrays/s", "value": round(rays_total / dt / 1e6, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"C3: atrium stand-in ({mesh.n_triangles} tris) {W}x{H}@{args.spp}spp B={args.bounces} diffuse BSDF + sky NEE/MIS + bluenoise, "
+                               f"64x64 tiles over {world} GPU(s), one gather", "rays_per_frame": int(rays_total / max(args.steps, 1)),
+                   "extension_rays_per_frame": int(ext_total / max(args.steps, 1)), "shadow_rays_per_frame": int(sh_total / max(args.steps, 1)),
+                   "device": pt.ctx.device_name},
+        "roofline": roofline,
+    }
+
+    # ---- CPU baseline (rank 0, N=1 only): the oracle path-traces a centred crop of the SAME frame
+    if rank == 0 and world == 1 and not args.no_cpu:
+        import orc
+
+        cw, ch = (int(x) for x in args.cpu_crop.split("x"))
+        cw, ch = min(cw, W), min(ch, H)
+        x0, y0 = (W - cw) // 2, (H - ch) // 2
+        rect = (x0, y0, x0 + cw, y0 + ch)
+        threads = os.cpu_count() or 1
+        osc = orc.Scene(mesh, sky, bn)
+        og = orc.GConst()
+        C.memmove(C.byref(og), C.byref(g_last), 304)
+        ogb, odepth = osc.gbuffer(og, rect=rect, threads=threads)
+        tc = time.perf_counter()
+        olight, counts = osc.reference_mode(og, ogb, odepth, rect=rect, threads=threads)
+        cdt = time.perf_counter() - tc
+        crays = float(counts[0] + counts[1])
+        glight = pt.light()
+        a = glight[y0:y0 + ch, x0:x0 + cw, :3].astype(np.float64)
+        b = olight[y0:y0 + ch, x0:x0 + cw, :3].astype(np.float64)
+        out["cpu_baseline"] = {"value": round(crays / cdt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                               "sample": f"oracle refrence_mode pass on the centred {cw}x{ch} crop of the same {W}x{H}@{args.spp}spp frame "
+                                         f"({int(crays)} rays, {cdt:.1f} s)"}
+        out["rmse_vs_oracle"] = float(np.sqrt(np.mean((a - b) ** 2)))
+        out["crop_bit_exact"] = bool(np.array_equal(glight[y0:y0 + ch, x0:x0 + cw].view(np.uint32), olight[y0:y0 + ch, x0:x0 + cw].view(np.uint32)))
+        # traversal-count cross-check: GPU counters vs oracle counters on the crop's primary rays
+        ys, xs = np.mgrid[y0:y0 + ch, x0:x0 + cw]
+        pr = orc.primary_rays(og, xs.ravel()[::7], ys.ravel()[::7])
+        _, _, _, _, gn, gt, _ = pt.ctx.trace_rays(pr, counts=True)
+        _, _, _, _, on, ot = osc.trace_closest(pr, threads=threads, counts=True)
+        out["roofline"]["counts_match_oracle"] = bool(np.array_equal(gn, on) and np.array_equal(gt, ot))
+
+    if rank == 0:
+        print(json.dumps(out))
+    pt.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,181 @@
+/*
+ * rt3.h -- C ABI of librt3.so: the MI355X (gfx950) wavefront path tracer that stands in for the reference's
+ * Vulkan ray-tracing passes.  Plain pointers and sizes only; every entry point cites the reference interface it
+ * replaces (paths relative to DerEchteKarsten/RayTracer3).  INTEGRATION.md shows the Rust `extern "C"` block a
+ * maintainer would add on the reference side.
+ *
+ * Conventions:
+ *  - every call returns 0 on success or a negative RT3_E_* code; rt3_last_error() gives the text; nothing aborts or
+ *    throws across the ABI (the reference `.unwrap()`s on its frame path, render_graph/mod.rs:601-610);
+ *  - a context is NOT re-entrant: call it from one thread at a time (the reference's renderer systems are chained on
+ *    the main thread, renderer/mod.rs:108-116); one context drives one GPU on one HIP stream;
+ *  - host pointers are borrowed for the duration of the call and copied synchronously (like DynamicBuffer::push,
+ *    vulkan/buffer.rs:406-420); device memory is owned by the context and released by rt3_destroy();
+ *  - resource handles are u32 `tag << 30 | index` exactly like DescriptorResourceHandle (bindless/mod.rs:67-77):
+ *    tag 0 = storage buffer, 1 = storage image, 3 = acceleration structure.
+ */
+#ifndef RT3_H
+#define RT3_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT3_OK 0
+#define RT3_E_INVALID (-1)     /* bad argument / unknown pass / wrong binding count */
+#define RT3_E_HIP (-2)         /* a HIP runtime call failed (text in rt3_last_error) */
+#define RT3_E_NO_DEVICE (-3)   /* no gfx950 device visible */
+#define RT3_E_STATE (-4)       /* call order (e.g. pass launched before rt3_accel_build) */
+#define RT3_E_UNSUPPORTED (-5) /* e.g. base-colour textures (round 1) */
+#define RT3_E_DEPTH (-6)       /* BVH deeper than the traversal stack supports */
+
+#define RT3_INVALID_HANDLE 0xFFFFFFFFu
+#define RT3_TAG_BUFFER 0u
+#define RT3_TAG_IMAGE 1u
+#define RT3_TAG_ACCEL 3u
+#define RT3_MISS 0xFFFFFFFFu
+#define RT3_BACKGROUND_DEPTH 100000.0f /* shaders/include/datatypes.slang:3 */
+
+/* image formats (subset of the vk::Format values the reference passes use) */
+#define RT3_FORMAT_R32_SFLOAT 100u          /* depth / gbuffer_depth (renderer/mod.rs:80, gbuffer.slang:6) */
+#define RT3_FORMAT_R32G32B32A32_SFLOAT 109u /* Light / PrevLight / color (refrence_mode.slang:10-11) */
+#define RT3_FORMAT_R32G32B32A32_UINT 107u   /* packed G-buffer (gbuffer.slang:5) */
+#define RT3_FORMAT_R8G8B8A8_UNORM 37u       /* display image */
+
+/* feature flags carried in GConst.pad[0]; 0 = reference semantics (diffuse BSDF, emissive-only transport,
+ * 2 random draws per bounce, refrence_mode.slang:36-57).  The others are north_star additions. */
+#define RT3_F_NEE_SKY 1u     /* next-event estimation + MIS against the equirect sky */
+#define RT3_F_BLUENOISE 2u   /* Cranley-Patterson shift by resources/bluenoise.png */
+#define RT3_F_SPECULAR 4u    /* reserved: layered GGX (brdf.slang:141-311) */
+#define RT3_F_FACEFORWARD 8u /* flip the shading normal towards the incoming ray */
+
+/* src/renderer/mod.rs:47-63 == shaders/include/datatypes.slang:28-43.  304 bytes, 16-byte aligned, column-major
+ * matrices.  Offsets 0,64,128,192,256,264,268,272,276,280,284,288,296. */
+typedef struct rt3_gconst {
+    float proj[16];
+    float view[16];
+    float proj_inverse[16];
+    float view_inverse[16];
+    float window_size[2];
+    uint32_t frame;
+    float blendfactor;
+    uint32_t bounces;
+    uint32_t samples;
+    uint32_t proberng;
+    float cell_size;
+    uint32_t mouse[2];
+    uint32_t pad[2]; /* pad[0] = RT3_F_* flags, pad[1] reserved (0) */
+} rt3_gconst;
+
+/* shaders/include/datatypes.slang:11-19 (52 bytes of fields, padded to 64 for float4 alignment) */
+typedef struct rt3_geometry_info {
+    float base_color[4];
+    int32_t base_color_texture_index; /* must be -1 in this round (RT3_E_UNSUPPORTED otherwise) */
+    float metallic_factor;
+    uint32_t index_offset;
+    uint32_t vertex_offset;
+    float emission[4];
+    float roughness;
+    uint32_t _pad[3];
+} rt3_geometry_info;
+
+/* frame statistics (no reference equivalent: the reference has no counters) */
+typedef struct rt3_stats {
+    uint64_t extension_rays; /* closest-hit rays traced since rt3_stats_reset (primary + bounce) */
+    uint64_t shadow_rays;    /* any-hit rays traced */
+    uint64_t nodes_visited;  /* by k_extend; only when counting is enabled (RT3_OPT_COUNT_TRAVERSAL) */
+    uint64_t tris_tested;
+    uint64_t shadow_nodes_visited; /* by k_shadow */
+    uint64_t shadow_tris_tested;
+    uint64_t extend_launches; /* k_extend launches */
+    double extend_ms;         /* sum of HIP-event durations of k_extend launches (RT3_OPT_PROFILE) */
+    uint64_t shadow_launches;
+    double shadow_ms;
+    double shade_ms;
+    double other_ms;
+} rt3_stats;
+
+typedef struct rt3_ctx rt3_ctx;
+
+/* ---- context: Context::new + RayTracingContext::new + BindlessDescriptorHeap::new + RenderGraph::new
+ *      (renderer/mod.rs:32-45, vulkan/mod.rs:86-231) -> hipSetDevice + one stream ---- */
+int rt3_create(int device, rt3_ctx **out);
+void rt3_destroy(rt3_ctx *ctx);
+const char *rt3_last_error(rt3_ctx *ctx); /* ctx may be NULL: last creation error */
+int rt3_device_name(rt3_ctx *ctx, char *buf, size_t buf_size);
+
+#define RT3_OPT_BATCH_SPP 1       /* samples per wavefront batch (0 = auto) */
+#define RT3_OPT_PROFILE 2         /* 1: bracket kernels with HIP events on the context's stream */
+#define RT3_OPT_COUNT_TRAVERSAL 3 /* 1: k_extend/k_shadow also count nodes / triangles (slower; for roofline bytes) */
+#define RT3_OPT_EXTEND_VARIANT 4  /* traversal kernel variant (0 = default) */
+int rt3_set_option(rt3_ctx *ctx, int option, int64_t value);
+
+/* ---- scene upload: DynamicBuffer::push (vulkan/buffer.rs:406-420) into the world buffers of
+ *      world/mod.rs:103-125 (vertex / index / geometry), plus the two north_star inputs ---- */
+int rt3_scene_set_vertices(rt3_ctx *ctx, const float *interleaved_p_n_t, uint32_t n_vertices); /* Vertex, assets/mod.rs:127-133 */
+int rt3_scene_set_indices(rt3_ctx *ctx, const uint32_t *indices, uint32_t n_indices);
+int rt3_scene_set_geometry(rt3_ctx *ctx, const rt3_geometry_info *infos, const uint32_t *prim_counts, uint32_t n);
+int rt3_scene_set_sky(rt3_ctx *ctx, const float *rgb, uint32_t width, uint32_t height);     /* main.rs:94 (commented skybox2.exr) */
+int rt3_scene_set_bluenoise(rt3_ctx *ctx, const uint8_t *rgba, uint32_t width, uint32_t height); /* resources/bluenoise.png */
+
+/* ---- acceleration structure: create_acceleration_structure (vulkan/raytracing.rs:88-148) -> GPU LBVH.
+ *      Returns the handle (tag 3) in *out_handle, like the TLAS registered at bindless/mod.rs:314-337 ---- */
+int rt3_accel_build(rt3_ctx *ctx, uint32_t *out_handle);
+/* introspection for parity tests: copy the BVH to the host (nodes: n_nodes x 64 B, tris: n_tris x 48 B) */
+int rt3_accel_info(rt3_ctx *ctx, uint32_t *n_nodes, uint32_t *n_tris, uint32_t *max_depth);
+int rt3_accel_download(rt3_ctx *ctx, void *nodes, size_t nodes_bytes, void *tris, size_t tris_bytes);
+int rt3_sky_download(rt3_ctx *ctx, float *cdf_cond, float *cdf_marg, float *pdf_uv); /* w*h, h, w*h floats */
+
+/* ---- resources: RenderGraph::image / buffer / import (render_graph/mod.rs:422-483) ---- */
+int rt3_buffer_create(rt3_ctx *ctx, size_t bytes, uint32_t *out_handle);
+int rt3_image_create(rt3_ctx *ctx, uint32_t width, uint32_t height, uint32_t format, uint32_t *out_handle);
+int rt3_image_import(rt3_ctx *ctx, void *device_ptr, uint32_t width, uint32_t height, uint32_t format, uint32_t *out_handle);
+int rt3_resource_upload(rt3_ctx *ctx, uint32_t handle, const void *src, size_t bytes);
+int rt3_resource_download(rt3_ctx *ctx, uint32_t handle, void *dst, size_t bytes); /* headless stand-in for present */
+int rt3_resource_device_ptr(rt3_ctx *ctx, uint32_t handle, void **out_ptr, size_t *out_bytes);
+
+/* ---- framebuffer partition (north_star): 64x64 tiles, Z-order over the tile grid, tile i -> rank i % n_ranks.
+ *      Passes only touch the pixels owned by `rank`.  Default: rank 0 of 1. ---- */
+int rt3_set_tile_partition(rt3_ctx *ctx, uint32_t width, uint32_t height, uint32_t rank, uint32_t n_ranks);
+int rt3_tile_pixel_count(rt3_ctx *ctx, uint32_t rank, uint32_t n_ranks, uint32_t *out_count);
+/* gather support: image (full window) <-> contiguous per-rank tile buffer (count x 16 bytes, device memory) */
+int rt3_image_pack_tiles(rt3_ctx *ctx, uint32_t image, uint32_t rank, uint32_t n_ranks, void *dst_device);
+int rt3_image_unpack_tiles(rt3_ctx *ctx, uint32_t image, uint32_t rank, uint32_t n_ranks, const void *src_device);
+
+/* ---- pass launch: ExecutionTrait::execute (render_graph/mod.rs:80-91) of a RayTracingPass / ComputePass node
+ *      (render_graph/executions.rs:15-55,80-121) -> RayTracingPipelineHandle::launch(x, y) /
+ *      ComputePipelineHandle::dispatch(x, y, z) (pipeline_cache/mod.rs:24-76).
+ *      `pass_name` is the shader path the reference would load from ./shaders/bin/{path}.slang.spv
+ *      (pipeline_cache/mod.rs:278-279); `constants` is the raw GConst blob (build.rs:66-94); `bindings` is the ordered
+ *      handle list of the node's non-attachment edges (bake.rs:51-83):
+ *        "gbuffer"       (x,y)=window   bindings {gbuffer RGBA32UI, gbuffer_depth R32F}                (gbuffer.slang:5-6)
+ *        "refrence_mode" (x,y)=window   bindings {gbuffer, gbuffer_depth, Light, PrevLight}            (refrence_mode.slang:8-11)
+ *        "postprocess"   (x,y,z)=groups of 8x8  bindings {Depth, Out RGBA32F, In RGBA32F}             (postprocess.slang:5-7)
+ *      Work is enqueued on the context's stream and returns immediately. ---- */
+int rt3_pass_launch(rt3_ctx *ctx, const char *pass_name, const char *entry, uint32_t x, uint32_t y, uint32_t z,
+                    const void *constants, size_t constants_size, const uint32_t *bindings, uint32_t n_bindings);
+/* timeline-semaphore wait of begin_frame (render_graph/mod.rs:656-665) -> hipStreamSynchronize */
+int rt3_frame_wait(rt3_ctx *ctx);
+
+/* ---- traversal on a caller-supplied ray batch (`trace()` call sites gbuffer.slang:13, refrence_mode.slang:54):
+ *      rays = 8 SoA arrays of n floats (ox,oy,oz,dx,dy,dz,tmin,tmax) in HOST memory; results to host.
+ *      any_hit = 0: closest hit -> t,u,v,prim ; any_hit = 1: prim[i] = 1 if occluded else 0 (t,u,v untouched).
+ *      n_nodes / n_tris (may be NULL) receive per-ray traversal counts.  `repeat` > 1 re-launches the kernel for timing;
+ *      *kernel_ms (may be NULL) receives the average HIP-event duration of one launch. ---- */
+int rt3_trace_rays(rt3_ctx *ctx, const float *rays, uint32_t n, int any_hit, float *t, float *u, float *v, uint32_t *prim,
+                   uint32_t *n_nodes, uint32_t *n_tris, int repeat, double *kernel_ms);
+
+int rt3_stats_reset(rt3_ctx *ctx);
+int rt3_stats_get(rt3_ctx *ctx, rt3_stats *out); /* synchronises the stream */
+
+/* ---- host helpers mirroring Camera::view_matrix / projection_matrix (components/camera.rs:52-58) and the GConst fill
+ *      of renderer::commands (renderer/mod.rs:72-78) ---- */
+void rt3_camera_gconst(const float position[3], const float direction[3], float fov_y_radians, float aspect,
+                       float z_near, float z_far, float width, float height, rt3_gconst *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

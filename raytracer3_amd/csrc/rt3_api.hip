@@ -1,0 +1,941 @@
+// rt3_api.hip -- host layer + C ABI of librt3.so (include/rt3.h).
+//
+// One context = one GPU + one HIP stream.  It owns the world buffers (world/mod.rs:103-125), the LBVH
+// (raytracing.rs:88-148), the name-less resource table with bindless-style handles (bindless/mod.rs:67-77) and the
+// wavefront work queues.  rt3_pass_launch() is the drop-in for executing one pass node of the reference's frame graph
+// (render_graph/mod.rs:80-107): the pass name selects a HIP kernel sequence instead of a SPIR-V pipeline.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt3.h"
+#include "rt3_internal.hpp"
+
+using namespace rt3;
+
+static_assert(sizeof(rt3_gconst) == 304 && sizeof(GConstDev) == 304, "GConst is 304 bytes (renderer/mod.rs:47-63)");
+static_assert(sizeof(rt3_geometry_info) == 64, "geometry info is 64 bytes");
+static_assert(RT3_F_NEE_SKY == RT3_FLAG_NEE_SKY && RT3_F_BLUENOISE == RT3_FLAG_BLUENOISE && RT3_F_FACEFORWARD == RT3_FLAG_FACEFORWARD, "flags");
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Resource {
+    uint32_t tag = 0;
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    uint32_t w = 0, h = 0, format = 0;
+    bool owned = true;
+};
+struct PixelList {
+    uint32_t w, h, rank, n_ranks, count;
+    uint32_t* dev;
+};
+enum Cat { CAT_EXTEND = 0, CAT_SHADOW = 1, CAT_SHADE = 2, CAT_OTHER = 3 };
+struct Timed {
+    hipEvent_t a, b;
+    int cat;
+};
+struct CounterBlock {  // device counters of one refrence_mode / gbuffer launch, harvested lazily
+    uint32_t first, n_ext, n_sh;  // slots [first, first+n_ext) are extension-queue sizes, then n_sh shadow-queue sizes
+};
+
+}  // namespace
+
+struct rt3_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    char name[256] = {0};
+    // scene
+    float* d_verts = nullptr;
+    uint32_t n_verts = 0;
+    uint32_t* d_indices = nullptr;
+    uint32_t n_indices = 0;
+    GeometryInfoDev* d_geoms = nullptr;
+    uint32_t n_geoms = 0, n_prims = 0;
+    uint32_t *d_prim_geom = nullptr, *d_first_prim = nullptr;
+    float *d_sky = nullptr, *d_cdf_cond = nullptr, *d_cdf_marg = nullptr, *d_pdf_uv = nullptr;
+    uint32_t sky_w = 0, sky_h = 0;
+    uint8_t* d_bn = nullptr;
+    uint32_t bn_w = 0, bn_h = 0;
+    LbvhResult bvh;
+    bool accel_built = false;
+    uint32_t max_index_seen = 0;
+    // resources
+    std::vector<Resource> resources;
+    std::vector<PixelList> pixlists;
+    uint32_t rank = 0, n_ranks = 1, part_w = 0, part_h = 0;
+    // work queues (capacity in paths)
+    size_t cap = 0, cap_pix = 0;
+    float *rays[2] = {nullptr, nullptr}, *hits = nullptr, *T[2] = {nullptr, nullptr};
+    uint32_t* pid[2] = {nullptr, nullptr};
+    float *sh_rays = nullptr, *sh_contrib = nullptr, *lacc = nullptr, *radsum = nullptr;
+    uint32_t* sh_pid = nullptr;
+    uint32_t* d_counters = nullptr;
+    uint32_t counters_cap = 1 << 16, counters_next = 0;
+    unsigned long long* d_totals = nullptr;
+    std::vector<CounterBlock> pending_counters;
+    // options / stats
+    int64_t opt_batch_spp = 0;
+    bool opt_profile = false, opt_count = false;
+    int opt_variant = 0;
+    rt3_stats stats;
+    uint64_t primary_rays_pending = 0;
+    std::vector<Timed> pending_events;
+    std::vector<Timed> free_events;
+};
+
+namespace {
+
+int fail(rt3_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+#define HIPC(ctx, call)                                                                                              \
+    do {                                                                                                             \
+        hipError_t e_ = (call);                                                                                      \
+        if (e_ != hipSuccess) return fail(ctx, RT3_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+template <typename T>
+int dev_alloc(rt3_ctx* c, T** p, size_t count) {
+    if (*p) {
+        (void)hipFree(*p);
+        *p = nullptr;
+    }
+    HIPC(c, hipMalloc((void**)p, (count ? count : 1) * sizeof(T)));
+    return RT3_OK;
+}
+template <typename T>
+void dev_free(T*& p) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+}
+
+uint32_t compact1by1(uint32_t x) {
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu;
+    x = (x | (x >> 8)) & 0x0000FFFFu;
+    return x;
+}
+// 64x64 tiles, Z-order over the tile grid, tile i -> rank i % n_ranks; Z-order inside a tile (primary-ray coherence)
+void tile_pixels(uint32_t w, uint32_t h, uint32_t rank, uint32_t n_ranks, std::vector<uint32_t>& out) {
+    out.clear();
+    uint32_t tw = (w + 63) / 64, th = (h + 63) / 64, side = 1, tile_no = 0;
+    while (side < tw || side < th) side *= 2;
+    for (uint32_t z = 0; z < side * side; z++) {
+        uint32_t tx = compact1by1(z), ty = compact1by1(z >> 1);
+        if (tx >= tw || ty >= th) continue;
+        uint32_t owner = tile_no++ % n_ranks;
+        if (owner != rank) continue;
+        for (uint32_t k = 0; k < 4096; k++) {
+            uint32_t x = tx * 64 + compact1by1(k), y = ty * 64 + compact1by1(k >> 1);
+            if (x < w && y < h) out.push_back(x | (y << 16));
+        }
+    }
+}
+int get_pixlist(rt3_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_t n_ranks, PixelList** out) {
+    for (auto& p : c->pixlists)
+        if (p.w == w && p.h == h && p.rank == rank && p.n_ranks == n_ranks) {
+            *out = &p;
+            return RT3_OK;
+        }
+    if (w == 0 || h == 0 || w > 65535 || h > 65535 || n_ranks == 0 || rank >= n_ranks) return fail(c, RT3_E_INVALID, "bad window / rank for tile partition");
+    std::vector<uint32_t> px;
+    tile_pixels(w, h, rank, n_ranks, px);
+    PixelList pl{w, h, rank, n_ranks, (uint32_t)px.size(), nullptr};
+    HIPC(c, hipMalloc((void**)&pl.dev, (px.size() ? px.size() : 1) * 4));
+    if (!px.empty()) HIPC(c, hipMemcpy(pl.dev, px.data(), px.size() * 4, hipMemcpyHostToDevice));
+    c->pixlists.push_back(pl);
+    *out = &c->pixlists.back();
+    return RT3_OK;
+}
+
+Resource* get_res(rt3_ctx* c, uint32_t handle, uint32_t want_tag) {
+    uint32_t tag = handle >> 30, idx = handle & 0x3FFFFFFFu;
+    if (tag != want_tag || idx >= c->resources.size()) return nullptr;
+    Resource* r = &c->resources[idx];
+    return r->tag == want_tag && r->ptr ? r : nullptr;
+}
+size_t format_bytes(uint32_t f) {
+    switch (f) {
+        case RT3_FORMAT_R32_SFLOAT: return 4;
+        case RT3_FORMAT_R32G32B32A32_SFLOAT: return 16;
+        case RT3_FORMAT_R32G32B32A32_UINT: return 16;
+        case RT3_FORMAT_R8G8B8A8_UNORM: return 4;
+        default: return 0;
+    }
+}
+
+SceneDev scene_dev(const rt3_ctx* c) {
+    SceneDev s;
+    s.verts = c->d_verts;
+    s.indices = c->d_indices;
+    s.geoms = c->d_geoms;
+    s.prim_geom = c->d_prim_geom;
+    s.first_prim = c->d_first_prim;
+    s.sky = c->d_sky;
+    s.cdf_cond = c->d_cdf_cond;
+    s.cdf_marg = c->d_cdf_marg;
+    s.pdf_uv = c->d_pdf_uv;
+    s.sky_w = c->sky_w;
+    s.sky_h = c->sky_h;
+    s.bluenoise = c->d_bn;
+    s.bn_w = c->bn_w;
+    s.bn_h = c->bn_h;
+    return s;
+}
+
+int ensure_work(rt3_ctx* c, size_t paths, size_t npix) {
+    if (paths > c->cap) {
+        size_t P = (paths + 255) & ~(size_t)255;
+        for (int k = 0; k < 2; k++) {
+            if (int r = dev_alloc(c, &c->rays[k], 8 * P)) return r;
+            if (int r = dev_alloc(c, &c->T[k], 4 * P)) return r;
+            if (int r = dev_alloc(c, &c->pid[k], P)) return r;
+        }
+        if (int r = dev_alloc(c, &c->hits, 4 * P)) return r;
+        if (int r = dev_alloc(c, &c->sh_rays, 8 * P)) return r;
+        if (int r = dev_alloc(c, &c->sh_contrib, 3 * P)) return r;
+        if (int r = dev_alloc(c, &c->sh_pid, P)) return r;
+        if (int r = dev_alloc(c, &c->lacc, 3 * P)) return r;
+        c->cap = P;
+    }
+    if (npix > c->cap_pix) {
+        if (int r = dev_alloc(c, &c->radsum, 3 * npix)) return r;
+        c->cap_pix = npix;
+    }
+    return RT3_OK;
+}
+
+int harvest(rt3_ctx* c) {  // stream must be idle
+    if (!c->pending_counters.empty()) {
+        std::vector<uint32_t> h(c->counters_next);
+        HIPC(c, hipMemcpy(h.data(), c->d_counters, (size_t)c->counters_next * 4, hipMemcpyDeviceToHost));
+        for (auto& b : c->pending_counters) {
+            for (uint32_t k = 0; k < b.n_ext; k++) c->stats.extension_rays += h[b.first + k];
+            for (uint32_t k = 0; k < b.n_sh; k++) c->stats.shadow_rays += h[b.first + b.n_ext + k];
+        }
+        c->pending_counters.clear();
+    }
+    c->counters_next = 0;
+    c->stats.extension_rays += c->primary_rays_pending;
+    c->primary_rays_pending = 0;
+    if (c->opt_count) {
+        unsigned long long t[4] = {0, 0, 0, 0};
+        HIPC(c, hipMemcpy(t, c->d_totals, 32, hipMemcpyDeviceToHost));
+        c->stats.nodes_visited += t[0];
+        c->stats.tris_tested += t[1];
+        c->stats.shadow_nodes_visited += t[2];
+        c->stats.shadow_tris_tested += t[3];
+        HIPC(c, hipMemset(c->d_totals, 0, 32));
+    }
+    for (auto& t : c->pending_events) {
+        float ms = 0.0f;
+        HIPC(c, hipEventElapsedTime(&ms, t.a, t.b));
+        switch (t.cat) {
+            case CAT_EXTEND: c->stats.extend_ms += ms; c->stats.extend_launches++; break;
+            case CAT_SHADOW: c->stats.shadow_ms += ms; c->stats.shadow_launches++; break;
+            case CAT_SHADE: c->stats.shade_ms += ms; break;
+            default: c->stats.other_ms += ms; break;
+        }
+        c->free_events.push_back(t);
+    }
+    c->pending_events.clear();
+    return RT3_OK;
+}
+
+struct ScopedTimer {  // brackets one kernel launch with HIP events on the context's stream when profiling is on
+    rt3_ctx* c;
+    Timed t;
+    bool on;
+    ScopedTimer(rt3_ctx* ctx, int cat) : c(ctx), on(ctx->opt_profile) {
+        if (!on) return;
+        if (!c->free_events.empty()) {
+            t = c->free_events.back();
+            c->free_events.pop_back();
+        } else if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) {
+            on = false;
+            return;
+        }
+        t.cat = cat;
+        (void)hipEventRecord(t.a, c->stream);
+    }
+    ~ScopedTimer() {
+        if (!on) return;
+        (void)hipEventRecord(t.b, c->stream);
+        c->pending_events.push_back(t);
+    }
+};
+
+int reserve_counters(rt3_ctx* c, uint32_t n, uint32_t* first) {
+    if (c->counters_next + n > c->counters_cap) {
+        HIPC(c, hipStreamSynchronize(c->stream));
+        if (int r = harvest(c)) return r;
+    }
+    if (n > c->counters_cap) return fail(c, RT3_E_INVALID, "too many bounces x batches for the counter block");
+    *first = c->counters_next;
+    c->counters_next += n;
+    HIPC(c, hipMemsetAsync(c->d_counters + *first, 0, (size_t)n * 4, c->stream));
+    return RT3_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- passes
+int check_window(rt3_ctx* c, const rt3_gconst* g, uint32_t* W, uint32_t* H) {
+    float fw = g->window_size[0], fh = g->window_size[1];
+    if (!(fw >= 1.0f && fh >= 1.0f && fw <= 65535.0f && fh <= 65535.0f) || fw != std::floor(fw) || fh != std::floor(fh))
+        return fail(c, RT3_E_INVALID, "GConst.window_size must hold integral pixel counts in [1, 65535]");
+    *W = (uint32_t)fw;
+    *H = (uint32_t)fh;
+    return RT3_OK;
+}
+Resource* image_checked(rt3_ctx* c, uint32_t handle, uint32_t W, uint32_t H, uint32_t format, const char* what) {
+    Resource* r = get_res(c, handle, RT3_TAG_IMAGE);
+    if (!r || r->w != W || r->h != H || r->format != format) {
+        c->err = std::string("binding '") + what + "' is not a " + std::to_string(W) + "x" + std::to_string(H) + " image of the expected format";
+        return nullptr;
+    }
+    return r;
+}
+
+// gbuffer.slang:8-21
+int pass_gbuffer(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y, const uint32_t* b, uint32_t nb) {
+    uint32_t W, H;
+    if (int r = check_window(c, g, &W, &H)) return r;
+    if (x != W || y != H) return fail(c, RT3_E_INVALID, "gbuffer: launch size must be the window size (WorkSize2D::FullScreen, executions.rs:73)");
+    if (nb != 2) return fail(c, RT3_E_INVALID, "gbuffer expects 2 bindings {gbuffer, gbuffer_depth}");
+    Resource* gb = image_checked(c, b[0], W, H, RT3_FORMAT_R32G32B32A32_UINT, "gbuffer");
+    Resource* dp = image_checked(c, b[1], W, H, RT3_FORMAT_R32_SFLOAT, "gbuffer_depth");
+    if (!gb || !dp) return RT3_E_INVALID;
+    PixelList* pl;
+    if (int r = get_pixlist(c, W, H, c->rank, c->n_ranks, &pl)) return r;
+    if (pl->count == 0) return RT3_OK;
+    if (int r = ensure_work(c, pl->count, pl->count)) return r;
+    GConstDev gd;
+    memcpy(&gd, g, sizeof(gd));
+    size_t S = c->cap;
+    {
+        ScopedTimer t(c, CAT_OTHER);
+        launch_raygen(c->stream, gd, pl->dev, pl->count, c->rays[0], S);
+    }
+    {
+        ScopedTimer t(c, CAT_EXTEND);
+        launch_extend(c->stream, c->opt_count, c->bvh.nodes, c->bvh.tris, c->rays[0], S, nullptr, pl->count, pl->count, c->hits, nullptr, nullptr,
+                      c->opt_count ? c->d_totals : nullptr);
+    }
+    c->primary_rays_pending += pl->count;
+    {
+        ScopedTimer t(c, CAT_OTHER);
+        launch_gbuffer(c->stream, scene_dev(c), pl->dev, pl->count, W, c->hits, S, gb->ptr, (float*)dp->ptr);
+    }
+    HIPC(c, hipGetLastError());
+    return RT3_OK;
+}
+
+// refrence_mode.slang:14-66 as a wavefront loop
+int pass_reference_mode(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y, const uint32_t* b, uint32_t nb) {
+    uint32_t W, H;
+    if (int r = check_window(c, g, &W, &H)) return r;
+    if (x != W || y != H) return fail(c, RT3_E_INVALID, "refrence_mode: launch size must be the window size");
+    if (nb != 4) return fail(c, RT3_E_INVALID, "refrence_mode expects 4 bindings {gbuffer, gbuffer_depth, Light, PrevLight}");
+    Resource* gb = image_checked(c, b[0], W, H, RT3_FORMAT_R32G32B32A32_UINT, "gbuffer");
+    Resource* dp = image_checked(c, b[1], W, H, RT3_FORMAT_R32_SFLOAT, "gbuffer_depth");
+    Resource* li = image_checked(c, b[2], W, H, RT3_FORMAT_R32G32B32A32_SFLOAT, "Light");
+    Resource* pv = image_checked(c, b[3], W, H, RT3_FORMAT_R32G32B32A32_SFLOAT, "PrevLight");
+    if (!gb || !dp || !li || !pv) return RT3_E_INVALID;
+    if (g->pad[0] & RT3_F_SPECULAR) return fail(c, RT3_E_UNSUPPORTED, "RT3_F_SPECULAR is not implemented in this round");
+    const uint32_t Sspp = g->samples, B = g->bounces;
+    if (Sspp == 0 || B == 0) return RT3_OK;  // GConst::default() leaves samples = bounces = 0 (renderer/mod.rs:47-63): nothing to trace
+    if (B > 64) return fail(c, RT3_E_INVALID, "bounces > 64");
+    PixelList* pl;
+    if (int r = get_pixlist(c, W, H, c->rank, c->n_ranks, &pl)) return r;
+    const uint32_t npix = pl->count;
+    if (npix == 0) return RT3_OK;
+    uint64_t max_paths = 1ull << 25;
+    uint32_t sb = c->opt_batch_spp > 0 ? (uint32_t)c->opt_batch_spp : (uint32_t)std::max<uint64_t>(1, max_paths / npix);
+    if (sb > Sspp) sb = Sspp;
+    if ((uint64_t)sb * npix > 0xFFFFFF00ull) return fail(c, RT3_E_INVALID, "batch too large");
+    if (int r = ensure_work(c, (size_t)sb * npix, npix)) return r;
+    const size_t S = c->cap;
+    GConstDev gd;
+    memcpy(&gd, g, sizeof(gd));
+    const bool nee = (g->pad[0] & RT3_F_NEE_SKY) && c->d_sky;
+    SceneDev sc = scene_dev(c);
+    for (uint32_t s0 = 0; s0 < Sspp; s0 += sb) {
+        const uint32_t nsb = std::min(sb, Sspp - s0);
+        const uint32_t n_first = nsb * npix;
+        uint32_t first;
+        if (int r = reserve_counters(c, 2 * B, &first)) return r;
+        uint32_t* ext_cnt = c->d_counters + first;   // [b] = extension rays emitted at bounce b (b < B-1)
+        uint32_t* sh_cnt = c->d_counters + first + B;  // [b] = shadow rays emitted at bounce b
+        c->pending_counters.push_back(CounterBlock{first, B, B});
+        int cur = 0;
+        for (uint32_t bn = 0; bn < B; bn++) {
+            ShadeLaunch L;
+            L.g = gd; L.sc = sc; L.pixels = pl->dev; L.npix = npix; L.width = W; L.s0 = s0; L.bounce = bn;
+            L.gbuffer = gb->ptr; L.depth = (const float*)dp->ptr;
+            L.in_rays = c->rays[cur]; L.in_hits = c->hits; L.in_T = c->T[cur]; L.in_pid = c->pid[cur];
+            L.in_count = bn ? ext_cnt + (bn - 1) : nullptr; L.n_first = n_first;
+            L.out_rays = c->rays[cur ^ 1]; L.out_T = c->T[cur ^ 1]; L.out_pid = c->pid[cur ^ 1]; L.out_count = ext_cnt + bn;
+            L.sh_rays = c->sh_rays; L.sh_contrib = c->sh_contrib; L.sh_pid = c->sh_pid; L.sh_count = sh_cnt + bn;
+            L.lacc = c->lacc; L.stride = S; L.max_n = n_first;
+            {
+                ScopedTimer t(c, CAT_SHADE);
+                launch_shade(c->stream, bn == 0, L);
+            }
+            cur ^= 1;
+            if (nee) {
+                ScopedTimer t(c, CAT_SHADOW);
+                launch_shadow(c->stream, c->opt_count, c->bvh.nodes, c->bvh.tris, c->sh_rays, S, sh_cnt + bn, 0, n_first, c->sh_contrib, c->sh_pid,
+                              c->lacc, S, nullptr, nullptr, nullptr, c->opt_count ? c->d_totals + 2 : nullptr);
+            }
+            if (bn != B - 1) {
+                ScopedTimer t(c, CAT_EXTEND);
+                launch_extend(c->stream, c->opt_count, c->bvh.nodes, c->bvh.tris, c->rays[cur], S, ext_cnt + bn, 0, n_first, c->hits, nullptr, nullptr,
+                              c->opt_count ? c->d_totals : nullptr);
+            }
+        }
+        {
+            ScopedTimer t(c, CAT_OTHER);
+            launch_accumulate(c->stream, gd, pl->dev, npix, W, (const float*)dp->ptr, c->lacc, S, nsb, s0 == 0, s0 + nsb >= Sspp, c->radsum, li->ptr,
+                              pv->ptr);
+        }
+    }
+    HIPC(c, hipGetLastError());
+    return RT3_OK;
+}
+
+// postprocess.slang:90-112
+int pass_postprocess(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y, uint32_t z, const uint32_t* b, uint32_t nb) {
+    uint32_t W, H;
+    if (int r = check_window(c, g, &W, &H)) return r;
+    if (x != (W + 7) / 8 || y != (H + 7) / 8 || z != 1)
+        return fail(c, RT3_E_INVALID, "postprocess: dispatch must be ceil(W/8) x ceil(H/8) x 1 groups (DispatchSize::FullScreen, build.rs:254-258)");
+    if (nb != 3) return fail(c, RT3_E_INVALID, "postprocess expects 3 bindings {Depth, Out, In}");
+    Resource* dp = image_checked(c, b[0], W, H, RT3_FORMAT_R32_SFLOAT, "Depth");
+    Resource* out = image_checked(c, b[1], W, H, RT3_FORMAT_R32G32B32A32_SFLOAT, "Out");
+    Resource* in = image_checked(c, b[2], W, H, RT3_FORMAT_R32G32B32A32_SFLOAT, "In");
+    if (!dp || !out || !in) return RT3_E_INVALID;
+    PixelList* pl;
+    if (int r = get_pixlist(c, W, H, c->rank, c->n_ranks, &pl)) return r;
+    if (pl->count == 0) return RT3_OK;
+    GConstDev gd;
+    memcpy(&gd, g, sizeof(gd));
+    ScopedTimer t(c, CAT_OTHER);
+    launch_postprocess(c->stream, gd, scene_dev(c), pl->dev, pl->count, W, (const float*)dp->ptr, in->ptr, out->ptr);
+    HIPC(c, hipGetLastError());
+    return RT3_OK;
+}
+
+}  // namespace
+
+// ================================================================================================== C ABI
+extern "C" {
+
+int rt3_create(int device, rt3_ctx** out) {
+    if (!out) return fail(nullptr, RT3_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(nullptr, RT3_E_NO_DEVICE, "no HIP device visible (librt3 has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(nullptr, RT3_E_INVALID, "device index out of range");
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(nullptr, RT3_E_HIP, "hipSetDevice failed");
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(nullptr, RT3_E_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", librt3 is built for gfx950 only");
+    rt3_ctx* c = new rt3_ctx();
+    c->device = device;
+    snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
+    memset(&c->stats, 0, sizeof(c->stats));
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&c->d_counters, (size_t)c->counters_cap * 4) != hipSuccess ||
+        hipMalloc((void**)&c->d_totals, 32) != hipSuccess || hipMemset(c->d_totals, 0, 32) != hipSuccess) {
+        delete c;
+        return fail(nullptr, RT3_E_HIP, "stream / counter allocation failed");
+    }
+    *out = c;
+    return RT3_OK;
+}
+
+void rt3_destroy(rt3_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    dev_free(c->d_verts); dev_free(c->d_indices); dev_free(c->d_geoms); dev_free(c->d_prim_geom); dev_free(c->d_first_prim);
+    dev_free(c->d_sky); dev_free(c->d_cdf_cond); dev_free(c->d_cdf_marg); dev_free(c->d_pdf_uv); dev_free(c->d_bn);
+    dev_free(c->bvh.nodes); dev_free(c->bvh.tris);
+    for (auto& r : c->resources)
+        if (r.owned && r.ptr) (void)hipFree(r.ptr);
+    for (auto& p : c->pixlists) (void)hipFree(p.dev);
+    for (int k = 0; k < 2; k++) { dev_free(c->rays[k]); dev_free(c->T[k]); dev_free(c->pid[k]); }
+    dev_free(c->hits); dev_free(c->sh_rays); dev_free(c->sh_contrib); dev_free(c->sh_pid); dev_free(c->lacc); dev_free(c->radsum);
+    dev_free(c->d_counters); dev_free(c->d_totals);
+    for (auto& t : c->pending_events) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    for (auto& t : c->free_events) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* rt3_last_error(rt3_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int rt3_device_name(rt3_ctx* c, char* buf, size_t n) {
+    if (!c || !buf || !n) return RT3_E_INVALID;
+    snprintf(buf, n, "%s", c->name);
+    return RT3_OK;
+}
+
+int rt3_set_option(rt3_ctx* c, int option, int64_t value) {
+    if (!c) return RT3_E_INVALID;
+    switch (option) {
+        case RT3_OPT_BATCH_SPP: c->opt_batch_spp = value; return RT3_OK;
+        case RT3_OPT_PROFILE: c->opt_profile = value != 0; return RT3_OK;
+        case RT3_OPT_COUNT_TRAVERSAL: c->opt_count = value != 0; return RT3_OK;
+        case RT3_OPT_EXTEND_VARIANT: c->opt_variant = (int)value; return RT3_OK;
+        default: return fail(c, RT3_E_INVALID, "unknown option");
+    }
+}
+
+// ---- scene
+int rt3_scene_set_vertices(rt3_ctx* c, const float* v, uint32_t n) {
+    if (!c || (!v && n)) return fail(c, RT3_E_INVALID, "vertices NULL");
+    HIPC(c, hipSetDevice(c->device));
+    if (int r = dev_alloc(c, &c->d_verts, (size_t)n * 8)) return r;
+    if (n) HIPC(c, hipMemcpy(c->d_verts, v, (size_t)n * 32, hipMemcpyHostToDevice));
+    c->n_verts = n;
+    c->accel_built = false;
+    return RT3_OK;
+}
+int rt3_scene_set_indices(rt3_ctx* c, const uint32_t* idx, uint32_t n) {
+    if (!c || (!idx && n)) return fail(c, RT3_E_INVALID, "indices NULL");
+    HIPC(c, hipSetDevice(c->device));
+    if (int r = dev_alloc(c, &c->d_indices, (size_t)n)) return r;
+    if (n) HIPC(c, hipMemcpy(c->d_indices, idx, (size_t)n * 4, hipMemcpyHostToDevice));
+    c->n_indices = n;
+    uint32_t mx = 0;
+    for (uint32_t i = 0; i < n; i++) mx = idx[i] > mx ? idx[i] : mx;
+    c->max_index_seen = mx;
+    c->accel_built = false;
+    return RT3_OK;
+}
+int rt3_scene_set_geometry(rt3_ctx* c, const rt3_geometry_info* g, const uint32_t* prim_counts, uint32_t n) {
+    if (!c || ((!g || !prim_counts) && n)) return fail(c, RT3_E_INVALID, "geometry NULL");
+    HIPC(c, hipSetDevice(c->device));
+    std::vector<uint32_t> first(n ? n : 1), pg;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (g[i].base_color_texture_index > -1) return fail(c, RT3_E_UNSUPPORTED, "base-colour textures are not supported in this round (hit_logic.slang:31-33)");
+        // bounds: the kernels index the world buffers without checks (a GPU fault would take the node down)
+        if ((uint64_t)g[i].index_offset + 3ull * prim_counts[i] > c->n_indices) return fail(c, RT3_E_INVALID, "geometry index range exceeds the index buffer");
+        if ((uint64_t)g[i].vertex_offset + c->max_index_seen >= (uint64_t)c->n_verts && prim_counts[i])
+            return fail(c, RT3_E_INVALID, "geometry vertex range exceeds the vertex buffer (set vertices and indices before geometry)");
+        first[i] = (uint32_t)total;
+        total += prim_counts[i];
+    }
+    if (total > 0x7FFFFFFFull) return fail(c, RT3_E_INVALID, "too many primitives");
+    pg.resize(total ? total : 1);
+    for (uint32_t i = 0; i < n; i++)
+        for (uint32_t k = 0; k < prim_counts[i]; k++) pg[first[i] + k] = i;
+    if (int r = dev_alloc(c, &c->d_geoms, (size_t)n)) return r;
+    if (int r = dev_alloc(c, &c->d_first_prim, (size_t)n)) return r;
+    if (int r = dev_alloc(c, &c->d_prim_geom, (size_t)total)) return r;
+    if (n) {
+        HIPC(c, hipMemcpy(c->d_geoms, g, (size_t)n * 64, hipMemcpyHostToDevice));
+        HIPC(c, hipMemcpy(c->d_first_prim, first.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    }
+    if (total) HIPC(c, hipMemcpy(c->d_prim_geom, pg.data(), (size_t)total * 4, hipMemcpyHostToDevice));
+    c->n_geoms = n;
+    c->n_prims = (uint32_t)total;
+    c->accel_built = false;
+    return RT3_OK;
+}
+// sky importance tables (north_star): f = (luminance + 1e-6) * sin(theta); conditional CDF per row, marginal CDF over
+// rows, pdf in (u,v).  Accumulated in double on the host, stored as float.
+int rt3_scene_set_sky(rt3_ctx* c, const float* rgb, uint32_t w, uint32_t h) {
+    if (!c || !rgb || !w || !h) return fail(c, RT3_E_INVALID, "sky NULL / empty");
+    HIPC(c, hipSetDevice(c->device));
+    const size_t n = (size_t)w * h;
+    std::vector<float> cond(n), pdf(n), marg(h);
+    std::vector<double> rows(h);
+    double total = 0.0;
+    for (uint32_t y = 0; y < h; y++) {
+        const double st = std::sin(3.14159265358979323846 * ((double)y + 0.5) / (double)h);
+        double acc = 0.0;
+        for (uint32_t x = 0; x < w; x++) {
+            const float* p = rgb + 3 * ((size_t)y * w + x);
+            const float lum = p[0] * 0.299f + p[1] * 0.587f + p[2] * 0.114f;  // luminance(), math.slang:119-122
+            const double f = ((double)lum + 1e-6) * st;
+            pdf[(size_t)y * w + x] = (float)f;
+            acc += f;
+            cond[(size_t)y * w + x] = (float)acc;
+        }
+        rows[y] = acc;
+        total += acc;
+    }
+    double run = 0.0;
+    for (uint32_t y = 0; y < h; y++) {
+        const float inv = (float)(1.0 / rows[y]);
+        for (uint32_t x = 0; x < w; x++) cond[(size_t)y * w + x] *= inv;
+        cond[(size_t)y * w + w - 1] = 1.0f;
+        run += rows[y];
+        marg[y] = (float)(run / total);
+    }
+    marg[h - 1] = 1.0f;
+    const float norm = (float)((double)w * (double)h / total);
+    for (size_t i = 0; i < n; i++) pdf[i] *= norm;
+    if (int r = dev_alloc(c, &c->d_sky, 3 * n)) return r;
+    if (int r = dev_alloc(c, &c->d_cdf_cond, n)) return r;
+    if (int r = dev_alloc(c, &c->d_pdf_uv, n)) return r;
+    if (int r = dev_alloc(c, &c->d_cdf_marg, (size_t)h)) return r;
+    HIPC(c, hipMemcpy(c->d_sky, rgb, n * 12, hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(c->d_cdf_cond, cond.data(), n * 4, hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(c->d_pdf_uv, pdf.data(), n * 4, hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(c->d_cdf_marg, marg.data(), (size_t)h * 4, hipMemcpyHostToDevice));
+    c->sky_w = w;
+    c->sky_h = h;
+    return RT3_OK;
+}
+int rt3_scene_set_bluenoise(rt3_ctx* c, const uint8_t* rgba, uint32_t w, uint32_t h) {
+    if (!c || !rgba || !w || !h) return fail(c, RT3_E_INVALID, "bluenoise NULL / empty");
+    HIPC(c, hipSetDevice(c->device));
+    if (int r = dev_alloc(c, &c->d_bn, (size_t)w * h * 4)) return r;
+    HIPC(c, hipMemcpy(c->d_bn, rgba, (size_t)w * h * 4, hipMemcpyHostToDevice));
+    c->bn_w = w;
+    c->bn_h = h;
+    return RT3_OK;
+}
+int rt3_sky_download(rt3_ctx* c, float* cond, float* marg, float* pdf) {
+    if (!c || !c->d_sky) return fail(c, RT3_E_STATE, "no sky set");
+    size_t n = (size_t)c->sky_w * c->sky_h;
+    if (cond) HIPC(c, hipMemcpy(cond, c->d_cdf_cond, n * 4, hipMemcpyDeviceToHost));
+    if (marg) HIPC(c, hipMemcpy(marg, c->d_cdf_marg, (size_t)c->sky_h * 4, hipMemcpyDeviceToHost));
+    if (pdf) HIPC(c, hipMemcpy(pdf, c->d_pdf_uv, n * 4, hipMemcpyDeviceToHost));
+    return RT3_OK;
+}
+
+// ---- acceleration structure
+int rt3_accel_build(rt3_ctx* c, uint32_t* out_handle) {
+    if (!c) return RT3_E_INVALID;
+    HIPC(c, hipSetDevice(c->device));
+    if (c->n_prims && (!c->d_verts || !c->d_indices)) return fail(c, RT3_E_STATE, "set vertices, indices and geometry before rt3_accel_build");
+    HIPC(c, hipStreamSynchronize(c->stream));
+    dev_free(c->bvh.nodes);
+    dev_free(c->bvh.tris);
+    hipError_t e = lbvh_build(c->stream, c->d_verts, c->d_indices, c->d_geoms, c->d_prim_geom, c->d_first_prim, c->n_prims, &c->bvh);
+    if (e != hipSuccess) return fail(c, RT3_E_HIP, std::string("lbvh_build: ") + hipGetErrorString(e));
+    if (c->bvh.max_depth > kMaxBvhDepth) {
+        dev_free(c->bvh.nodes);
+        dev_free(c->bvh.tris);
+        return fail(c, RT3_E_DEPTH, "LBVH depth " + std::to_string(c->bvh.max_depth) + " exceeds the traversal stack (" + std::to_string(kMaxBvhDepth) + ")");
+    }
+    c->accel_built = true;
+    if (out_handle) *out_handle = (RT3_TAG_ACCEL << 30) | 0u;
+    return RT3_OK;
+}
+int rt3_accel_info(rt3_ctx* c, uint32_t* n_nodes, uint32_t* n_tris, uint32_t* max_depth) {
+    if (!c || !c->accel_built) return fail(c, RT3_E_STATE, "no acceleration structure built");
+    if (n_nodes) *n_nodes = c->bvh.n_nodes;
+    if (n_tris) *n_tris = c->bvh.n_tris;
+    if (max_depth) *max_depth = c->bvh.max_depth;
+    return RT3_OK;
+}
+int rt3_accel_download(rt3_ctx* c, void* nodes, size_t nodes_bytes, void* tris, size_t tris_bytes) {
+    if (!c || !c->accel_built) return fail(c, RT3_E_STATE, "no acceleration structure built");
+    if (nodes) {
+        if (nodes_bytes != (size_t)c->bvh.n_nodes * 64) return fail(c, RT3_E_INVALID, "nodes_bytes mismatch");
+        if (nodes_bytes) HIPC(c, hipMemcpy(nodes, c->bvh.nodes, nodes_bytes, hipMemcpyDeviceToHost));
+    }
+    if (tris) {
+        if (tris_bytes != (size_t)c->bvh.n_tris * 48) return fail(c, RT3_E_INVALID, "tris_bytes mismatch");
+        if (tris_bytes) HIPC(c, hipMemcpy(tris, c->bvh.tris, tris_bytes, hipMemcpyDeviceToHost));
+    }
+    return RT3_OK;
+}
+
+// ---- resources
+int rt3_buffer_create(rt3_ctx* c, size_t bytes, uint32_t* out) {
+    if (!c || !out || !bytes) return fail(c, RT3_E_INVALID, "bad buffer size");
+    HIPC(c, hipSetDevice(c->device));
+    Resource r;
+    r.tag = RT3_TAG_BUFFER;
+    r.bytes = bytes;
+    HIPC(c, hipMalloc(&r.ptr, bytes));
+    HIPC(c, hipMemset(r.ptr, 0, bytes));
+    c->resources.push_back(r);
+    *out = (RT3_TAG_BUFFER << 30) | (uint32_t)(c->resources.size() - 1);
+    return RT3_OK;
+}
+int rt3_image_create(rt3_ctx* c, uint32_t w, uint32_t h, uint32_t format, uint32_t* out) {
+    size_t px = format_bytes(format);
+    if (!c || !out || !w || !h || !px) return fail(c, RT3_E_INVALID, "bad image size / format");
+    HIPC(c, hipSetDevice(c->device));
+    Resource r;
+    r.tag = RT3_TAG_IMAGE;
+    r.w = w; r.h = h; r.format = format;
+    r.bytes = (size_t)w * h * px;
+    HIPC(c, hipMalloc(&r.ptr, r.bytes));
+    HIPC(c, hipMemset(r.ptr, 0, r.bytes));
+    c->resources.push_back(r);
+    *out = (RT3_TAG_IMAGE << 30) | (uint32_t)(c->resources.size() - 1);
+    return RT3_OK;
+}
+int rt3_image_import(rt3_ctx* c, void* device_ptr, uint32_t w, uint32_t h, uint32_t format, uint32_t* out) {
+    size_t px = format_bytes(format);
+    if (!c || !out || !device_ptr || !w || !h || !px) return fail(c, RT3_E_INVALID, "bad import");
+    Resource r;
+    r.tag = RT3_TAG_IMAGE;
+    r.w = w; r.h = h; r.format = format;
+    r.bytes = (size_t)w * h * px;
+    r.ptr = device_ptr;
+    r.owned = false;
+    c->resources.push_back(r);
+    *out = (RT3_TAG_IMAGE << 30) | (uint32_t)(c->resources.size() - 1);
+    return RT3_OK;
+}
+static Resource* any_res(rt3_ctx* c, uint32_t handle) {
+    Resource* r = get_res(c, handle, RT3_TAG_IMAGE);
+    return r ? r : get_res(c, handle, RT3_TAG_BUFFER);
+}
+int rt3_resource_upload(rt3_ctx* c, uint32_t handle, const void* src, size_t bytes) {
+    if (!c || !src) return RT3_E_INVALID;
+    Resource* r = any_res(c, handle);
+    if (!r || bytes != r->bytes) return fail(c, RT3_E_INVALID, "upload: bad handle or size");
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemcpy(r->ptr, src, bytes, hipMemcpyHostToDevice));
+    return RT3_OK;
+}
+int rt3_resource_download(rt3_ctx* c, uint32_t handle, void* dst, size_t bytes) {
+    if (!c || !dst) return RT3_E_INVALID;
+    Resource* r = any_res(c, handle);
+    if (!r || bytes != r->bytes) return fail(c, RT3_E_INVALID, "download: bad handle or size");
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    HIPC(c, hipMemcpy(dst, r->ptr, bytes, hipMemcpyDeviceToHost));
+    return RT3_OK;
+}
+int rt3_resource_device_ptr(rt3_ctx* c, uint32_t handle, void** out_ptr, size_t* out_bytes) {
+    if (!c || !out_ptr) return RT3_E_INVALID;
+    Resource* r = any_res(c, handle);
+    if (!r) return fail(c, RT3_E_INVALID, "bad handle");
+    *out_ptr = r->ptr;
+    if (out_bytes) *out_bytes = r->bytes;
+    return RT3_OK;
+}
+
+// ---- tiles
+int rt3_set_tile_partition(rt3_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_t n_ranks) {
+    if (!c) return RT3_E_INVALID;
+    HIPC(c, hipSetDevice(c->device));
+    PixelList* pl;
+    if (int r = get_pixlist(c, w, h, rank, n_ranks, &pl)) return r;
+    c->rank = rank;
+    c->n_ranks = n_ranks;
+    c->part_w = w;
+    c->part_h = h;
+    return RT3_OK;
+}
+int rt3_tile_pixel_count(rt3_ctx* c, uint32_t rank, uint32_t n_ranks, uint32_t* out) {
+    if (!c || !out || !c->part_w) return fail(c, RT3_E_STATE, "call rt3_set_tile_partition first");
+    PixelList* pl;
+    if (int r = get_pixlist(c, c->part_w, c->part_h, rank, n_ranks, &pl)) return r;
+    *out = pl->count;
+    return RT3_OK;
+}
+int rt3_image_pack_tiles(rt3_ctx* c, uint32_t image, uint32_t rank, uint32_t n_ranks, void* dst) {
+    if (!c || !dst) return RT3_E_INVALID;
+    Resource* r = get_res(c, image, RT3_TAG_IMAGE);
+    if (!r || format_bytes(r->format) != 16) return fail(c, RT3_E_INVALID, "pack_tiles needs a 16-byte-per-pixel image");
+    HIPC(c, hipSetDevice(c->device));
+    PixelList* pl;
+    if (int e = get_pixlist(c, r->w, r->h, rank, n_ranks, &pl)) return e;
+    if (pl->count) launch_pack_tiles(c->stream, pl->dev, pl->count, r->w, r->ptr, dst);
+    HIPC(c, hipGetLastError());
+    return RT3_OK;
+}
+int rt3_image_unpack_tiles(rt3_ctx* c, uint32_t image, uint32_t rank, uint32_t n_ranks, const void* src) {
+    if (!c || !src) return RT3_E_INVALID;
+    Resource* r = get_res(c, image, RT3_TAG_IMAGE);
+    if (!r || format_bytes(r->format) != 16) return fail(c, RT3_E_INVALID, "unpack_tiles needs a 16-byte-per-pixel image");
+    HIPC(c, hipSetDevice(c->device));
+    PixelList* pl;
+    if (int e = get_pixlist(c, r->w, r->h, rank, n_ranks, &pl)) return e;
+    if (pl->count) launch_unpack_tiles(c->stream, pl->dev, pl->count, r->w, src, r->ptr);
+    HIPC(c, hipGetLastError());
+    return RT3_OK;
+}
+
+// ---- pass launch
+int rt3_pass_launch(rt3_ctx* c, const char* pass_name, const char* entry, uint32_t x, uint32_t y, uint32_t z, const void* constants,
+                    size_t constants_size, const uint32_t* bindings, uint32_t n_bindings) {
+    if (!c || !pass_name) return fail(c, RT3_E_INVALID, "pass_name NULL");
+    if (entry && strcmp(entry, "main") != 0) return fail(c, RT3_E_INVALID, std::string("unknown entry point '") + entry + "' (the reference passes use \"main\")");
+    if (!constants || constants_size != sizeof(rt3_gconst)) return fail(c, RT3_E_INVALID, "constants must be the 304-byte GConst block");
+    if (!bindings && n_bindings) return fail(c, RT3_E_INVALID, "bindings NULL");
+    if (!c->accel_built) return fail(c, RT3_E_STATE, "rt3_accel_build has not been called for the current scene");
+    HIPC(c, hipSetDevice(c->device));
+    rt3_gconst g;
+    memcpy(&g, constants, sizeof(g));
+    if (!strcmp(pass_name, "gbuffer")) return pass_gbuffer(c, &g, x, y, bindings, n_bindings);
+    if (!strcmp(pass_name, "refrence_mode")) return pass_reference_mode(c, &g, x, y, bindings, n_bindings);
+    if (!strcmp(pass_name, "postprocess")) return pass_postprocess(c, &g, x, y, z, bindings, n_bindings);
+    return fail(c, RT3_E_INVALID, std::string("unknown pass '") + pass_name + "' (known: gbuffer, refrence_mode, postprocess)");
+}
+int rt3_frame_wait(rt3_ctx* c) {
+    if (!c) return RT3_E_INVALID;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    return RT3_OK;
+}
+
+// ---- ray batches
+int rt3_trace_rays(rt3_ctx* c, const float* rays, uint32_t n, int any_hit, float* t, float* u, float* v, uint32_t* prim, uint32_t* n_nodes,
+                   uint32_t* n_tris, int repeat, double* kernel_ms) {
+    if (!c || !rays || !prim || (!any_hit && (!t || !u || !v))) return fail(c, RT3_E_INVALID, "trace_rays: NULL argument");
+    if (!c->accel_built) return fail(c, RT3_E_STATE, "rt3_accel_build has not been called for the current scene");
+    if (n == 0) return RT3_OK;
+    HIPC(c, hipSetDevice(c->device));
+    float *d_rays = nullptr, *d_hits = nullptr;
+    uint32_t *d_cn = nullptr, *d_ct = nullptr, *d_occ = nullptr;
+    const bool count = n_nodes || n_tris;
+    int rc = RT3_OK;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(d_rays); (void)hipFree(d_hits); (void)hipFree(d_cn); (void)hipFree(d_ct); (void)hipFree(d_occ);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    };
+#define TR(call)                                                                            \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            rc = fail(c, RT3_E_HIP, std::string(#call) + ": " + hipGetErrorString(e_));     \
+            cleanup();                                                                      \
+            return rc;                                                                      \
+        }                                                                                   \
+    } while (0)
+    TR(hipMalloc((void**)&d_rays, (size_t)n * 32));
+    TR(hipMalloc((void**)&d_hits, (size_t)n * 16));
+    TR(hipMalloc((void**)&d_occ, (size_t)n * 4));
+    if (count) {
+        TR(hipMalloc((void**)&d_cn, (size_t)n * 4));
+        TR(hipMalloc((void**)&d_ct, (size_t)n * 4));
+    }
+    TR(hipMemcpy(d_rays, rays, (size_t)n * 32, hipMemcpyHostToDevice));
+    TR(hipEventCreate(&e0));
+    TR(hipEventCreate(&e1));
+    if (repeat < 1) repeat = 1;
+    auto launch = [&]() {
+        if (any_hit)
+            launch_shadow(c->stream, count, c->bvh.nodes, c->bvh.tris, d_rays, n, nullptr, n, n, nullptr, nullptr, nullptr, 0, d_occ, d_cn, d_ct, nullptr);
+        else
+            launch_extend(c->stream, count, c->bvh.nodes, c->bvh.tris, d_rays, n, nullptr, n, n, d_hits, d_cn, d_ct, nullptr);
+    };
+    launch();  // warm-up (also the result-producing launch)
+    TR(hipEventRecord(e0, c->stream));
+    for (int k = 0; k < repeat; k++) launch();
+    TR(hipEventRecord(e1, c->stream));
+    TR(hipGetLastError());
+    TR(hipStreamSynchronize(c->stream));
+    float ms = 0.0f;
+    TR(hipEventElapsedTime(&ms, e0, e1));
+    if (kernel_ms) *kernel_ms = (double)ms / repeat;
+    if (any_hit) {
+        TR(hipMemcpy(prim, d_occ, (size_t)n * 4, hipMemcpyDeviceToHost));
+    } else {
+        TR(hipMemcpy(t, d_hits, (size_t)n * 4, hipMemcpyDeviceToHost));
+        TR(hipMemcpy(u, d_hits + n, (size_t)n * 4, hipMemcpyDeviceToHost));
+        TR(hipMemcpy(v, d_hits + 2 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost));
+        TR(hipMemcpy(prim, d_hits + 3 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost));
+    }
+    if (n_nodes) TR(hipMemcpy(n_nodes, d_cn, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if (n_tris) TR(hipMemcpy(n_tris, d_ct, (size_t)n * 4, hipMemcpyDeviceToHost));
+#undef TR
+    cleanup();
+    return RT3_OK;
+}
+
+int rt3_stats_reset(rt3_ctx* c) {
+    if (!c) return RT3_E_INVALID;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (int r = harvest(c)) return r;
+    memset(&c->stats, 0, sizeof(c->stats));
+    return RT3_OK;
+}
+int rt3_stats_get(rt3_ctx* c, rt3_stats* out) {
+    if (!c || !out) return RT3_E_INVALID;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    if (int r = harvest(c)) return r;
+    *out = c->stats;
+    return RT3_OK;
+}
+
+// ---- camera: components/camera.rs:52-58 (glam look_at_rh / perspective_rh with depth 0..1) + renderer/mod.rs:72-78
+static void invert4(const float* m, float* out) {
+    double a[4][4], inv[4][4];
+    for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++) a[r][c] = m[c * 4 + r];
+    // adjugate through 3x3 minors
+    auto minor3 = [&](int rr, int cc) {
+        double s[3][3];
+        int ri = 0;
+        for (int r = 0; r < 4; r++) {
+            if (r == rr) continue;
+            int ci = 0;
+            for (int c = 0; c < 4; c++) {
+                if (c == cc) continue;
+                s[ri][ci++] = a[r][c];
+            }
+            ri++;
+        }
+        return s[0][0] * (s[1][1] * s[2][2] - s[1][2] * s[2][1]) - s[0][1] * (s[1][0] * s[2][2] - s[1][2] * s[2][0]) +
+               s[0][2] * (s[1][0] * s[2][1] - s[1][1] * s[2][0]);
+    };
+    double det = 0.0;
+    for (int c = 0; c < 4; c++) det += ((c & 1) ? -1.0 : 1.0) * a[0][c] * minor3(0, c);
+    for (int r = 0; r < 4; r++)
+        for (int c = 0; c < 4; c++) inv[c][r] = (((r + c) & 1) ? -1.0 : 1.0) * minor3(r, c) / det;
+    for (int c = 0; c < 4; c++)
+        for (int r = 0; r < 4; r++) out[c * 4 + r] = (float)inv[r][c];
+}
+void rt3_camera_gconst(const float position[3], const float direction[3], float fov_y, float aspect, float z_near, float z_far, float width,
+                       float height, rt3_gconst* g) {
+    memset(g, 0, sizeof(*g));
+    float len = std::sqrt(direction[0] * direction[0] + direction[1] * direction[1] + direction[2] * direction[2]);
+    float f[3] = {direction[0] / len, direction[1] / len, direction[2] / len};  // Camera::new normalises, camera.rs:43
+    // look_to_rh(eye, dir, up=+Y): s = normalize(f x up), u = s x f
+    float s[3] = {f[1] * 0.0f - f[2] * 1.0f, f[2] * 0.0f - f[0] * 0.0f, f[0] * 1.0f - f[1] * 0.0f};
+    float sl = std::sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]);
+    s[0] /= sl; s[1] /= sl; s[2] /= sl;
+    float u[3] = {s[1] * f[2] - s[2] * f[1], s[2] * f[0] - s[0] * f[2], s[0] * f[1] - s[1] * f[0]};
+    float* v = g->view;
+    v[0] = s[0]; v[1] = u[0]; v[2] = -f[0];
+    v[4] = s[1]; v[5] = u[1]; v[6] = -f[1];
+    v[8] = s[2]; v[9] = u[2]; v[10] = -f[2];
+    v[12] = -(position[0] * s[0] + position[1] * s[1] + position[2] * s[2]);
+    v[13] = -(position[0] * u[0] + position[1] * u[1] + position[2] * u[2]);
+    v[14] = position[0] * f[0] + position[1] * f[1] + position[2] * f[2];
+    v[15] = 1.0f;
+    float sf = (float)std::sin(0.5 * (double)fov_y), cf = (float)std::cos(0.5 * (double)fov_y);
+    float hh = cf / sf, ww = hh / aspect, r = z_far / (z_near - z_far);
+    g->proj[0] = ww;
+    g->proj[5] = hh;
+    g->proj[10] = r;
+    g->proj[11] = -1.0f;
+    g->proj[14] = r * z_near;
+    invert4(g->proj, g->proj_inverse);
+    invert4(g->view, g->view_inverse);
+    g->window_size[0] = width;
+    g->window_size[1] = height;
+    g->blendfactor = 1.0f;
+}
+
+}  // extern "C"

@@ -1,0 +1,409 @@
+// rt3_device.hpp -- device-side arithmetic of the gfx950 wavefront path tracer.
+//
+// Each function names the reference shader lines it implements (paths relative to DerEchteKarsten/RayTracer3).
+// Arithmetic contract: fp32, compiled with -ffp-contract=off, IEEE divide/sqrt, min/max as explicit
+// selects, transcendental functions only through the polynomials below -- so results are reproducible bit for bit
+// on any IEEE-754 machine and can be checked exactly by the CPU oracle in tests.
+#pragma once
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RT3_DEV __device__ __forceinline__
+
+namespace rt3 {
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kTau = 6.28318530717958647692f;       // math.slang:3
+constexpr float kInvPi = 0.318309886183790671538f;    // math.slang:4
+constexpr float kHalfPi = 1.57079632679489661923f;
+constexpr float kBackgroundDepth = 100000.0f;         // datatypes.slang:3
+constexpr uint32_t kMiss = 0xFFFFFFFFu;
+constexpr float kRayTMin = 0.001f;                    // refrence_mode.slang:31
+
+struct V3 {
+    float x, y, z;
+};
+RT3_DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+RT3_DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+RT3_DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+RT3_DEV V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+RT3_DEV V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+RT3_DEV V3 neg(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+RT3_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT3_DEV V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+RT3_DEV V3 normalize(V3 a) {
+    float inv = 1.0f / __fsqrt_rn(dot(a, a));
+    return a * inv;
+}
+RT3_DEV float fmin_sel(float a, float b) { return a < b ? a : b; }
+RT3_DEV float fmax_sel(float a, float b) { return a > b ? a : b; }
+
+// ------------------------------------------------------------------------------------------------ RNG
+// random.slang:5-15
+RT3_DEV uint32_t jenkins_hash(uint32_t a) {
+    a = (a + 0x7ed55d16u) + (a << 12);
+    a = (a ^ 0xc761c23cu) ^ (a >> 19);
+    a = (a + 0x165667b1u) + (a << 5);
+    a = (a + 0xd3a2646cu) ^ (a << 9);
+    a = (a + 0xfd7046c5u) + (a << 3);
+    a = (a ^ 0xb55a4f09u) ^ (a >> 16);
+    return a;
+}
+// math.slang:105-117
+RT3_DEV uint32_t integer_explode(uint32_t x) {
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+RT3_DEV uint32_t zcurve(uint32_t x, uint32_t y) { return integer_explode(x) | (integer_explode(y) << 1); }
+// random.slang:42-46
+RT3_DEV uint32_t rng_seed(uint32_t px, uint32_t py, uint32_t frame) { return jenkins_hash(zcurve(px, py)) + frame; }
+// random.slang:49-79, counter passed explicitly (the stream is counter-based; see DESIGN.md for the index rule)
+RT3_DEV uint32_t murmur3(uint32_t seed, uint32_t index) {
+    uint32_t k = index * 0xcc9e2d51u;
+    k = (k << 15) | (k >> 17);
+    k *= 0x1b873593u;
+    uint32_t h = seed ^ k;
+    h = ((h << 13) | (h >> 19)) * 5u + 0xe6546b64u;
+    h ^= 4u;
+    h ^= h >> 16;
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    h *= 0xc2b2ae35u;
+    h ^= h >> 16;
+    return h;
+}
+// random.slang:82-89
+RT3_DEV float uniform_float(uint32_t seed, uint32_t index) {
+    return __uint_as_float((murmur3(seed, index) & 0x007FFFFFu) | 0x3F800000u) - 1.0f;
+}
+// Cranley-Patterson shift by one blue-noise byte (north_star): frac(u + c/256)
+RT3_DEV float bluenoise_shift(float u, uint32_t c) {
+    float r = u + (float)c * 0.00390625f;
+    return r >= 1.0f ? r - 1.0f : r;
+}
+
+// ------------------------------------------------------------------------------------------------ packing.slang
+RT3_DEV float unpack_unorm(uint32_t p, uint32_t bits) {  // :2-5
+    uint32_t maxv = (1u << bits) - 1u;
+    return (float)(p & maxv) / (float)maxv;
+}
+RT3_DEV uint32_t pack_unorm(float v, uint32_t bits) {  // :7-10
+    uint32_t maxv = (1u << bits) - 1u;
+    float c = fmin_sel(fmax_sel(v, 0.0f), 1.0f);
+    return (uint32_t)(c * (float)maxv + 0.5f);
+}
+RT3_DEV uint32_t pack_normal_11_10_11(V3 n) {  // :12-18
+    return pack_unorm(n.x * 0.5f + 0.5f, 11) + (pack_unorm(n.y * 0.5f + 0.5f, 10) << 11) + (pack_unorm(n.z * 0.5f + 0.5f, 11) << 21);
+}
+RT3_DEV V3 unpack_normal_11_10_11(uint32_t p) {  // :20-27
+    return normalize(v3(unpack_unorm(p, 11) * 2.0f - 1.0f, unpack_unorm(p >> 11, 10) * 2.0f - 1.0f, unpack_unorm(p >> 21, 11) * 2.0f - 1.0f));
+}
+RT3_DEV uint32_t pack_color_888(V3 c) {  // :46-53
+    return pack_unorm(__fsqrt_rn(c.x), 8) + (pack_unorm(__fsqrt_rn(c.y), 8) << 8) + (pack_unorm(__fsqrt_rn(c.z), 8) << 16);
+}
+RT3_DEV V3 unpack_color_888(uint32_t p) {  // :55-62
+    V3 c = v3(unpack_unorm(p, 8), unpack_unorm(p >> 8, 8), unpack_unorm(p >> 16, 8));
+    return c * c;
+}
+RT3_DEV uint32_t f32_to_f16_bits(float f) { return (uint32_t)__half_as_ushort(__float2half_rn(f)); }
+RT3_DEV float f16_bits_to_f32(uint32_t h) { return __half2float(__ushort_as_half((unsigned short)h)); }
+RT3_DEV uint32_t pack_2x16f(float a, float b) { return f32_to_f16_bits(a) | (f32_to_f16_bits(b) << 16); }  // :88-90
+RT3_DEV float exp2_int(int e) { return __uint_as_float((uint32_t)(e + 127) << 23); }
+RT3_DEV uint32_t float3_to_rgb9e5(V3 c) {  // :99-144
+    const float max_rgb9e5 = (511.0f / 512.0f) * 65536.0f;
+    float rc = fmin_sel(fmax_sel(c.x, 0.0f), max_rgb9e5), gc = fmin_sel(fmax_sel(c.y, 0.0f), max_rgb9e5), bc = fmin_sel(fmax_sel(c.z, 0.0f), max_rgb9e5);
+    float maxrgb = fmax_sel(rc, fmax_sel(gc, bc));
+    int fl2 = (int)((__float_as_uint(maxrgb) & 0x7F800000u) >> 23) - 127;
+    int exp_shared = (fl2 > -16 ? fl2 : -16) + 1 + 15;
+    float denom = exp2_int(exp_shared - 15 - 9);
+    int maxm = (int)floorf(maxrgb / denom + 0.5f);
+    if (maxm == 512) {
+        denom *= 2.0f;
+        exp_shared += 1;
+    }
+    int rm = (int)floorf(rc / denom + 0.5f), gm = (int)floorf(gc / denom + 0.5f), bm = (int)floorf(bc / denom + 0.5f);
+    return ((uint32_t)rm << 23) | ((uint32_t)gm << 14) | ((uint32_t)bm << 5) | (uint32_t)exp_shared;
+}
+RT3_DEV V3 rgb9e5_to_float3(uint32_t v) {  // :146-162
+    float scale = exp2_int((int)(v & 31u) - 24);
+    return v3((float)((v >> 23) & 511u) * scale, (float)((v >> 14) & 511u) * scale, (float)((v >> 5) & 511u) * scale);
+}
+
+// gbuffer_helpers.slang:5-71
+struct Surface {
+    V3 albedo, emissive, normal;
+    float roughness, metalness;
+};
+RT3_DEV uint4 gbuffer_pack(const Surface& s) {  // :22-34
+    return make_uint4(pack_color_888(s.albedo), pack_normal_11_10_11(s.normal), pack_2x16f(__fsqrt_rn(s.roughness), s.metalness),
+                      float3_to_rgb9e5(s.emissive));
+}
+RT3_DEV Surface gbuffer_unpack(uint4 p) {  // :59-70
+    Surface s;
+    s.albedo = unpack_color_888(p.x);
+    s.normal = unpack_normal_11_10_11(p.y);
+    float pr = f16_bits_to_f32(p.z & 0xFFFFu);
+    s.roughness = pr * pr;
+    s.metalness = f16_bits_to_f32((p.z >> 16) & 0xFFFFu);
+    s.emissive = rgb9e5_to_float3(p.w);
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------ math
+// sin(2 pi u), cos(2 pi u), u in [0,1): exact quadrant split, odd/even Taylor polynomials on [0, pi/4]
+RT3_DEV void sincos_2pi(float u, float& s_out, float& c_out) {
+    float x = u * 4.0f;
+    int q = (int)x;
+    float r = x - (float)q;
+    bool sw = r > 0.5f;
+    if (sw) r = 1.0f - r;
+    float a = r * kHalfPi, a2 = a * a;
+    float s = a * (1.0f + a2 * (-1.6666667163e-01f + a2 * (8.3333337680e-03f + a2 * (-1.9841270114e-04f + a2 * 2.7557314297e-06f))));
+    float c = 1.0f + a2 * (-0.5f + a2 * (4.1666667908e-02f + a2 * (-1.3888889225e-03f + a2 * (2.4801587642e-05f + a2 * -2.7557314297e-07f))));
+    float ss = sw ? c : s, cc = sw ? s : c;
+    q &= 3;
+    s_out = q == 0 ? ss : (q == 1 ? cc : (q == 2 ? -ss : -cc));
+    c_out = q == 0 ? cc : (q == 1 ? -ss : (q == 2 ? -cc : ss));
+}
+RT3_DEV float atan2_poly(float y, float x) {
+    float ax = x < 0.0f ? -x : x, ay = y < 0.0f ? -y : y;
+    float mx = fmax_sel(ax, ay), mn = fmin_sel(ax, ay);
+    if (mx == 0.0f) return 0.0f;
+    float a = mn / mx, s = a * a;
+    float r = a * (0.99997726f + s * (-0.33262347f + s * (0.19354346f + s * (-0.11643287f + s * (0.05265332f + s * -0.01172120f)))));
+    if (ay > ax) r = kHalfPi - r;
+    if (x < 0.0f) r = kPi - r;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+// math.slang:6-12
+RT3_DEV void direction_to_equirect_uv(V3 d, float& u, float& v) {
+    float as = atan2_poly(d.y, __fsqrt_rn(fmax_sel(0.0f, 1.0f - d.y * d.y)));
+    u = 0.5f + atan2_poly(d.z, d.x) / kTau;
+    v = 0.5f - as / kPi;
+}
+// math.slang:29-50 ; columns b1, b2 (third column is n)
+RT3_DEV void build_orthonormal_basis(V3 n, V3& b1, V3& b2) {
+    if (n.z < 0.0f) {
+        const float a = 1.0f / (1.0f - n.z);
+        const float b = n.x * n.y * a;
+        b1 = v3(1.0f - n.x * n.x * a, -b, n.x);
+        b2 = v3(b, n.y * n.y * a - 1.0f, -n.y);
+    } else {
+        const float a = 1.0f / (1.0f + n.z);
+        const float b = -n.x * n.y * a;
+        b1 = v3(1.0f - n.x * n.x * a, b, -n.x);
+        b2 = v3(b, 1.0f - n.y * n.y * a, -n.y);
+    }
+}
+// mul(tangent_to_world, wi), refrence_mode.slang:48
+RT3_DEV V3 basis_apply(V3 b1, V3 b2, V3 n, V3 w) {
+    return v3(b1.x * w.x + b2.x * w.y + n.x * w.z, b1.y * w.x + b2.y * w.y + n.y * w.z, b1.z * w.x + b2.z * w.y + n.z * w.z);
+}
+// brdf.slang:56-65 DiffuseBrdf::sample direction
+RT3_DEV V3 diffuse_sample(float u0, float u1) {
+    float sp, cp;
+    sincos_2pi(u0, sp, cp);
+    float cos_theta = __fsqrt_rn(fmax_sel(0.0f, 1.0f - u1));
+    float sin_theta = __fsqrt_rn(fmax_sel(0.0f, 1.0f - cos_theta * cos_theta));
+    return v3(cp * sin_theta, sp * sin_theta, cos_theta);
+}
+
+// ------------------------------------------------------------------------------------------------ camera / primary ray
+struct GConstDev {  // == rt3_gconst (renderer/mod.rs:47-63)
+    float proj[16], view[16], proj_inverse[16], view_inverse[16];
+    float window_size[2];
+    uint32_t frame;
+    float blendfactor;
+    uint32_t bounces, samples, proberng;
+    float cell_size;
+    uint32_t mouse[2], pad[2];
+};
+static_assert(sizeof(GConstDev) == 304, "GConst layout");
+
+// gbuffer_helpers.slang:85-103 (view_dir + setupPrimaryRay); pixel (0,0) top-left, upright image (d.y flipped)
+RT3_DEV void primary_ray(const GConstDev& g, uint32_t px, uint32_t py, V3& o, V3& d) {
+    float cx = ((float)px + 0.5f) / g.window_size[0], cy = ((float)py + 0.5f) / g.window_size[1];
+    float dx = cx * 2.0f - 1.0f, dy = -(cy * 2.0f - 1.0f);
+    const float* m = g.proj_inverse;
+    V3 target = v3(m[0] * dx + m[4] * dy + m[8] * 1.0f + m[12] * 1.0f, m[1] * dx + m[5] * dy + m[9] * 1.0f + m[13] * 1.0f,
+                   m[2] * dx + m[6] * dy + m[10] * 1.0f + m[14] * 1.0f);
+    V3 t = normalize(target);
+    const float* w = g.view_inverse;
+    d = v3(w[0] * t.x + w[4] * t.y + w[8] * t.z + w[12] * 0.0f, w[1] * t.x + w[5] * t.y + w[9] * t.z + w[13] * 0.0f,
+           w[2] * t.x + w[6] * t.y + w[10] * t.z + w[14] * 0.0f);
+    o = v3(w[12], w[13], w[14]);
+}
+
+// ------------------------------------------------------------------------------------------------ scene access
+struct GeometryInfoDev {  // datatypes.slang:11-19 padded to 64 B
+    float base_color[4];
+    int32_t tex;
+    float metallic;
+    uint32_t index_offset, vertex_offset;
+    float emission[4];
+    float roughness;
+    uint32_t pad[3];
+};
+static_assert(sizeof(GeometryInfoDev) == 64, "GeometryInfo layout");
+
+struct SceneDev {
+    const float* verts;          // interleaved p n t (8 floats)
+    const uint32_t* indices;
+    const GeometryInfoDev* geoms;
+    const uint32_t* prim_geom;   // global primitive -> geometry
+    const uint32_t* first_prim;  // geometry -> first global primitive
+    // sky
+    const float* sky;            // rgb
+    const float* cdf_cond;
+    const float* cdf_marg;
+    const float* pdf_uv;
+    uint32_t sky_w, sky_h;
+    const uint8_t* bluenoise;
+    uint32_t bn_w, bn_h;
+};
+
+// hit_logic.slang:5-40 (transform = identity, vertex colour = 1, no textures)
+RT3_DEV Surface hit_info(const SceneDev& sc, uint32_t prim, float bu, float bv) {
+    uint32_t g = sc.prim_geom[prim];
+    const GeometryInfoDev& gi = sc.geoms[g];
+    uint32_t io = gi.index_offset + 3u * (prim - sc.first_prim[g]);
+    const float* v0 = sc.verts + 8 * (size_t)(gi.vertex_offset + sc.indices[io]);
+    const float* v1 = sc.verts + 8 * (size_t)(gi.vertex_offset + sc.indices[io + 1]);
+    const float* v2 = sc.verts + 8 * (size_t)(gi.vertex_offset + sc.indices[io + 2]);
+    float b0 = 1.0f - bu - bv;
+    V3 n = v3(v0[3] * b0 + v1[3] * bu + v2[3] * bv, v0[4] * b0 + v1[4] * bu + v2[4] * bv, v0[5] * b0 + v1[5] * bu + v2[5] * bv);
+    n = normalize(normalize(n));  // :24 and :25
+    Surface s;
+    s.albedo = v3(gi.base_color[0], gi.base_color[1], gi.base_color[2]);
+    s.emissive = v3(gi.emission[0] * 12.0f, gi.emission[1] * 12.0f, gi.emission[2] * 12.0f);  // :36
+    s.normal = n;
+    s.roughness = gi.roughness;
+    s.metalness = gi.metallic;
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------ sky (north_star)
+RT3_DEV V3 sky_eval(const SceneDev& sc, float u, float v) {  // Skybox.SampleLevel(uv, 0): bilinear, wrap u, clamp v
+    if (!sc.sky) return v3(0.0f, 0.0f, 0.0f);
+    int W = (int)sc.sky_w, H = (int)sc.sky_h;
+    float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    float xf = floorf(x), yf = floorf(y);
+    float fx = x - xf, fy = y - yf;
+    int x0 = (int)xf, y0 = (int)yf, x1 = x0 + 1, y1 = y0 + 1;
+    x0 = ((x0 % W) + W) % W;
+    x1 = ((x1 % W) + W) % W;
+    y0 = y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0);
+    y1 = y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1);
+    const float* p00 = sc.sky + 3 * ((size_t)y0 * W + x0);
+    const float* p10 = sc.sky + 3 * ((size_t)y0 * W + x1);
+    const float* p01 = sc.sky + 3 * ((size_t)y1 * W + x0);
+    const float* p11 = sc.sky + 3 * ((size_t)y1 * W + x1);
+    float o[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float top = p00[k] * (1.0f - fx) + p10[k] * fx, bot = p01[k] * (1.0f - fx) + p11[k] * fx;
+        o[k] = top * (1.0f - fy) + bot * fy;
+    }
+    return v3(o[0], o[1], o[2]);
+}
+RT3_DEV float sky_pdf(const SceneDev& sc, float u, float v) {
+    if (!sc.sky) return 0.0f;
+    int W = (int)sc.sky_w, H = (int)sc.sky_h;
+    int ix = (int)(u * (float)W), iy = (int)(v * (float)H);
+    ix = ix < 0 ? 0 : (ix > W - 1 ? W - 1 : ix);
+    iy = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);
+    float st, ct;
+    sincos_2pi(v * 0.5f, st, ct);
+    if (!(st > 0.0f)) return 0.0f;
+    return sc.pdf_uv[(size_t)iy * W + ix] / (2.0f * kPi * kPi * st);
+}
+RT3_DEV uint32_t cdf_find(const float* cdf, uint32_t n, float u) {  // first index with cdf[i] > u
+    uint32_t lo = 0, hi = n - 1;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (cdf[mid] > u) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
+}
+RT3_DEV void sky_sample(const SceneDev& sc, float u0, float u1, V3& dir, V3& rad, float& pdf) {
+    uint32_t W = sc.sky_w, H = sc.sky_h;
+    uint32_t y = cdf_find(sc.cdf_marg, H, u0);
+    float lo = y > 0 ? sc.cdf_marg[y - 1] : 0.0f, hi = sc.cdf_marg[y];
+    float dv = hi > lo ? (u0 - lo) / (hi - lo) : 0.5f;
+    const float* row = sc.cdf_cond + (size_t)y * W;
+    uint32_t x = cdf_find(row, W, u1);
+    lo = x > 0 ? row[x - 1] : 0.0f;
+    hi = row[x];
+    float du = hi > lo ? (u1 - lo) / (hi - lo) : 0.5f;
+    float u = ((float)x + du) / (float)W, v = ((float)y + dv) / (float)H;
+    float st, ct, s2, c2;
+    sincos_2pi(v * 0.5f, st, ct);
+    sincos_2pi(u, s2, c2);
+    dir = v3((-c2) * st, ct, (-s2) * st);
+    rad = sky_eval(sc, u, v);
+    pdf = st > 0.0f ? sc.pdf_uv[(size_t)y * W + x] / (2.0f * kPi * kPi * st) : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------ intersection (north_star)
+struct Hit {
+    float t, u, v;
+    uint32_t prim;
+};
+// Moeller-Trumbore on (v0, e1, e2); tri = 3 x float4: {v0.xyz,e1.x} {e1.yz,e2.xy} {e2.z,prim,-,-}.  Two-sided.
+// Order-independent acceptance: t > tmin && (t < best.t || (t == best.t && prim < best.prim)).
+RT3_DEV void tri_test(float4 q0, float4 q1, float4 q2, V3 o, V3 d, float tmin, Hit& best) {
+    V3 v0 = v3(q0.x, q0.y, q0.z), e1 = v3(q0.w, q1.x, q1.y), e2 = v3(q1.z, q1.w, q2.x);
+    V3 pv = cross(d, e2);
+    float det = dot(e1, pv);
+    if (det == 0.0f) return;
+    float inv = 1.0f / det;
+    V3 tv = o - v0;
+    float u = dot(tv, pv) * inv;
+    if (!(u >= 0.0f && u <= 1.0f)) return;
+    V3 qv = cross(tv, e1);
+    float v = dot(d, qv) * inv;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return;
+    float t = dot(e2, qv) * inv;
+    uint32_t prim = __float_as_uint(q2.y);
+    if (t > tmin && (t < best.t || (t == best.t && prim < best.prim))) {
+        best.t = t;
+        best.u = u;
+        best.v = v;
+        best.prim = prim;
+    }
+}
+RT3_DEV float guarded_inverse(float d) {
+    float a = d < 0.0f ? -d : d;
+    float g = a < 1e-20f ? (d < 0.0f ? -1e-20f : 1e-20f) : d;
+    return 1.0f / g;
+}
+// slab test of one child box; returns hit and the entry distance
+RT3_DEV bool slab_test(V3 bmin, V3 bmax, V3 o, V3 inv, float tmin, float tbest, float& tn_out) {
+    float t0 = (bmin.x - o.x) * inv.x, t1 = (bmax.x - o.x) * inv.x;
+    float tn = tmin, tf = tbest;
+    float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
+    tn = lo > tn ? lo : tn;
+    tf = hi < tf ? hi : tf;
+    t0 = (bmin.y - o.y) * inv.y;
+    t1 = (bmax.y - o.y) * inv.y;
+    lo = t0 < t1 ? t0 : t1;
+    hi = t0 < t1 ? t1 : t0;
+    tn = lo > tn ? lo : tn;
+    tf = hi < tf ? hi : tf;
+    t0 = (bmin.z - o.z) * inv.z;
+    t1 = (bmax.z - o.z) * inv.z;
+    lo = t0 < t1 ? t0 : t1;
+    hi = t0 < t1 ? t1 : t0;
+    tn = lo > tn ? lo : tn;
+    tf = hi < tf ? hi : tf;
+    tn_out = tn;
+    return tn <= tf;
+}
+
+}  // namespace rt3

@@ -1,0 +1,74 @@
+// rt3_internal.hpp -- declarations shared by the kernel translation units and the C-ABI host layer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "rt3_device.hpp"
+
+#define RT3_FLAG_NEE_SKY 1u
+#define RT3_FLAG_BLUENOISE 2u
+#define RT3_FLAG_SPECULAR 4u
+#define RT3_FLAG_FACEFORWARD 8u
+
+namespace rt3 {
+
+constexpr int kExtendBlock = 256;          // threads per traversal workgroup (4 waves)
+constexpr unsigned kExtendMaxBlocks = 2048;  // 256 CUs x 8: grid-stride beyond that
+constexpr uint32_t kMaxBvhDepth = 64;      // LDS short stack (24) + private spill (40)
+
+struct ShadeLaunch {
+    GConstDev g;
+    SceneDev sc;
+    const uint32_t* pixels;
+    uint32_t npix, width, s0, bounce;
+    const void* gbuffer;
+    const float* depth;
+    const float* in_rays;
+    const float* in_hits;
+    const float* in_T;
+    const uint32_t* in_pid;
+    const uint32_t* in_count;
+    uint32_t n_first;
+    float* out_rays;
+    float* out_T;
+    uint32_t* out_pid;
+    uint32_t* out_count;
+    float* sh_rays;
+    float* sh_contrib;
+    uint32_t* sh_pid;
+    uint32_t* sh_count;
+    float* lacc;
+    size_t stride;
+    uint32_t max_n;  // upper bound of live paths (grid sizing)
+};
+
+void launch_raygen(hipStream_t st, const GConstDev& g, const uint32_t* pixels, uint32_t npix, float* rays, size_t stride);
+void launch_extend(hipStream_t st, bool count, const float4* nodes, const float4* tris, const float* rays, size_t stride,
+                   const uint32_t* count_ptr, uint32_t count_imm, uint32_t max_n, float* hits, uint32_t* cn, uint32_t* ct,
+                   unsigned long long* totals);
+void launch_shadow(hipStream_t st, bool count, const float4* nodes, const float4* tris, const float* rays, size_t stride,
+                   const uint32_t* count_ptr, uint32_t count_imm, uint32_t max_n, const float* contrib, const uint32_t* pid, float* lacc,
+                   size_t lstride, uint32_t* occluded_out, uint32_t* cn, uint32_t* ct, unsigned long long* totals);
+void launch_gbuffer(hipStream_t st, const SceneDev& sc, const uint32_t* pixels, uint32_t npix, uint32_t width, const float* hits,
+                    size_t stride, void* gbuffer, float* depth);
+void launch_shade(hipStream_t st, bool first, const ShadeLaunch& L);
+void launch_accumulate(hipStream_t st, const GConstDev& g, const uint32_t* pixels, uint32_t npix, uint32_t width, const float* depth,
+                       const float* lacc, size_t stride, uint32_t sb, int first_batch, int last_batch, float* radsum, void* light,
+                       const void* prev);
+void launch_postprocess(hipStream_t st, const GConstDev& g, const SceneDev& sc, const uint32_t* pixels, uint32_t npix, uint32_t width,
+                        const float* depth, const void* in, void* out);
+void launch_pack_tiles(hipStream_t st, const uint32_t* pixels, uint32_t npix, uint32_t width, const void* img, void* dst);
+void launch_unpack_tiles(hipStream_t st, const uint32_t* pixels, uint32_t npix, uint32_t width, const void* src, void* img);
+
+// LBVH build (rt3_lbvh.hip).  All pointers are device memory owned by the caller except the scratch the builder
+// allocates and frees itself.  Returns hipSuccess or the failing HIP error; *max_depth is read back to the host.
+struct LbvhResult {
+    float4* nodes = nullptr;   // n_nodes x 4 float4 (64 B)
+    float4* tris = nullptr;    // n_tris x 3 float4 (48 B), Morton order
+    uint32_t n_nodes = 0, n_tris = 0, max_depth = 0;
+};
+hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,
+                      const uint32_t* first_prim, uint32_t n_prims, LbvhResult* out);
+
+}  // namespace rt3

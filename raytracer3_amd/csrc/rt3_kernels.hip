@@ -1,0 +1,540 @@
+// rt3_kernels.hip -- gfx950 wavefront path-tracing kernels (hand-written HIP, wave64).
+//
+// Pipeline (replaces shaders/old/{gbuffer,refrence_mode,postprocess}.slang + the driver's ray traversal):
+//   k_raygen -> k_extend -> k_gbuffer                                   ("gbuffer" pass)
+//   k_shade<first> -> [k_shadow] -> k_extend -> k_shade -> ... -> k_accumulate   ("refrence_mode" pass)
+//   k_postprocess                                                        ("postprocess" pass)
+// All queues are structure-of-arrays so that lane i touches element i of each stream (coalesced 256 B per
+// wave-instruction); live rays are compacted with __ballot / popcount, one atomic per wave.
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include "rt3_device.hpp"
+#include "rt3_internal.hpp"
+
+namespace rt3 {
+
+// ------------------------------------------------------------------------------------------------ traversal
+// One ray per lane.  Short stack: kLdsStack entries per lane in LDS ([entry][lane] so a wave's ds_read_b32 /
+// ds_write_b32 hit 64 consecutive dwords: conflict-free), deeper entries spill to a private array (scratch).
+constexpr int kLdsStack = 24;
+constexpr int kSpill = 40;  // kLdsStack + kSpill >= kMaxBvhDepth (checked on the host after the build)
+constexpr uint32_t kMaxSteps = 1u << 20;  // safety bound on traversal steps per ray (a corrupt tree must not hang the GPU)
+
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ Hit traverse(const float4* __restrict__ nodes, const float4* __restrict__ tris, V3 o, V3 d,
+                                        float tmin, float tmax, uint32_t* __restrict__ lds, uint32_t& cn, uint32_t& ct) {
+    Hit best{tmax, 0.0f, 0.0f, kMiss};
+    if (nodes == nullptr) return best;
+    const V3 inv = v3(guarded_inverse(d.x), guarded_inverse(d.y), guarded_inverse(d.z));
+    uint32_t spill[kSpill];
+    int sp = 0;
+    uint32_t cur = 0;
+    // kMaxSteps bounds the walk so that a corrupt tree can never hang the GPU (a valid tree visits < 2 n nodes)
+    for (uint32_t step = 0; step < kMaxSteps; ++step) {
+        if (cur & 0x80000000u) {
+            const float4* tp = tris + 3 * (size_t)(cur & 0x7FFFFFFFu);
+            float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
+            if (COUNT) ct++;
+            tri_test(q0, q1, q2, o, d, tmin, best);
+            if (ANY && best.prim != kMiss) break;
+            if (sp == 0) break;
+            --sp;
+            cur = sp < kLdsStack ? lds[sp * kExtendBlock] : spill[sp - kLdsStack];
+            continue;
+        }
+        const float4* np = nodes + 4 * (size_t)cur;
+        float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+        if (COUNT) cn++;
+        float tn0, tn1;
+        bool h0 = slab_test(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), o, inv, tmin, best.t, tn0);
+        bool h1 = slab_test(v3(n1.z, n1.w, n2.x), v3(n2.y, n2.z, n2.w), o, inv, tmin, best.t, tn1);
+        uint32_t r0 = __float_as_uint(n3.x), r1 = __float_as_uint(n3.y);
+        if (h0 && h1) {
+            bool near1 = tn1 < tn0;
+            uint32_t far = near1 ? r0 : r1;
+            cur = near1 ? r1 : r0;
+            if (sp < kLdsStack) lds[sp * kExtendBlock] = far;
+            else spill[sp - kLdsStack] = far;
+            ++sp;
+        } else if (h0) {
+            cur = r0;
+        } else if (h1) {
+            cur = r1;
+        } else {
+            if (sp == 0) break;
+            --sp;
+            cur = sp < kLdsStack ? lds[sp * kExtendBlock] : spill[sp - kLdsStack];
+        }
+    }
+    return best;
+}
+
+// closest-hit over a ray queue.  rays: 8 SoA streams of `stride` floats; hits: t,u,v,prim streams of `stride`.
+template <bool COUNT>
+__global__ __launch_bounds__(kExtendBlock) void k_extend(const float4* __restrict__ nodes, const float4* __restrict__ tris,
+                                                         const float* __restrict__ rays, size_t stride,
+                                                         const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
+                                                         float* __restrict__ hits, uint32_t* __restrict__ cnt_nodes,
+                                                         uint32_t* __restrict__ cnt_tris, unsigned long long* __restrict__ totals) {
+    __shared__ uint32_t stack[kLdsStack * kExtendBlock];
+    const uint32_t n = count_ptr ? *count_ptr : count_imm;
+    unsigned long long tot_n = 0, tot_t = 0;
+    for (uint32_t i = blockIdx.x * kExtendBlock + threadIdx.x; i < n; i += gridDim.x * kExtendBlock) {
+        V3 o = v3(rays[i], rays[stride + i], rays[2 * stride + i]);
+        V3 d = v3(rays[3 * stride + i], rays[4 * stride + i], rays[5 * stride + i]);
+        float tmin = rays[6 * stride + i], tmax = rays[7 * stride + i];
+        uint32_t cn = 0, ct = 0;
+        Hit h = traverse<false, COUNT>(nodes, tris, o, d, tmin, tmax, stack + threadIdx.x, cn, ct);
+        hits[i] = h.t;
+        hits[stride + i] = h.u;
+        hits[2 * stride + i] = h.v;
+        reinterpret_cast<uint32_t*>(hits)[3 * stride + i] = h.prim;
+        if (COUNT) {
+            if (cnt_nodes) cnt_nodes[i] = cn;
+            if (cnt_tris) cnt_tris[i] = ct;
+            tot_n += cn;
+            tot_t += ct;
+        }
+    }
+    if (COUNT && totals) {
+        atomicAdd(&totals[0], tot_n);
+        atomicAdd(&totals[1], tot_t);
+    }
+}
+
+// any-hit over the shadow queue; unoccluded rays add their contribution to the path's radiance slot.
+// If `occluded_out` != nullptr the kernel only reports occlusion (rt3_trace_rays).
+template <bool COUNT>
+__global__ __launch_bounds__(kExtendBlock) void k_shadow(const float4* __restrict__ nodes, const float4* __restrict__ tris,
+                                                         const float* __restrict__ rays, size_t stride,
+                                                         const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
+                                                         const float* __restrict__ contrib, const uint32_t* __restrict__ pid,
+                                                         float* __restrict__ lacc, size_t lstride,
+                                                         uint32_t* __restrict__ occluded_out, uint32_t* __restrict__ cnt_nodes,
+                                                         uint32_t* __restrict__ cnt_tris, unsigned long long* __restrict__ totals) {
+    __shared__ uint32_t stack[kLdsStack * kExtendBlock];
+    const uint32_t n = count_ptr ? *count_ptr : count_imm;
+    unsigned long long tot_n = 0, tot_t = 0;
+    for (uint32_t i = blockIdx.x * kExtendBlock + threadIdx.x; i < n; i += gridDim.x * kExtendBlock) {
+        V3 o = v3(rays[i], rays[stride + i], rays[2 * stride + i]);
+        V3 d = v3(rays[3 * stride + i], rays[4 * stride + i], rays[5 * stride + i]);
+        float tmin = rays[6 * stride + i], tmax = rays[7 * stride + i];
+        uint32_t cn = 0, ct = 0;
+        Hit h = traverse<true, COUNT>(nodes, tris, o, d, tmin, tmax, stack + threadIdx.x, cn, ct);
+        if (occluded_out) {
+            occluded_out[i] = h.prim != kMiss ? 1u : 0u;
+        } else if (h.prim == kMiss) {
+            uint32_t p = pid[i];
+            lacc[p] += contrib[i];
+            lacc[lstride + p] += contrib[stride + i];
+            lacc[2 * lstride + p] += contrib[2 * stride + i];
+        }
+        if (COUNT) {
+            if (cnt_nodes) cnt_nodes[i] = cn;
+            if (cnt_tris) cnt_tris[i] = ct;
+            tot_n += cn;
+            tot_t += ct;
+        }
+    }
+    if (COUNT && totals) {
+        atomicAdd(&totals[0], tot_n);
+        atomicAdd(&totals[1], tot_t);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ gbuffer pass
+// gbuffer.slang:8-12 : primary rays for the pixels this rank owns (pixel list is in tile / Z-curve order)
+__global__ void k_raygen(GConstDev g, const uint32_t* __restrict__ pixels, uint32_t npix, float* __restrict__ rays, size_t stride) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        uint32_t xy = pixels[i];
+        V3 o, d;
+        primary_ray(g, xy & 0xFFFFu, xy >> 16, o, d);
+        rays[i] = o.x;
+        rays[stride + i] = o.y;
+        rays[2 * stride + i] = o.z;
+        rays[3 * stride + i] = d.x;
+        rays[4 * stride + i] = d.y;
+        rays[5 * stride + i] = d.z;
+        rays[6 * stride + i] = 0.0f;               // TMin, gbuffer_helpers.slang:100
+        rays[7 * stride + i] = kBackgroundDepth;   // TMax, :101
+    }
+}
+// gbuffer.slang:15-20
+__global__ void k_gbuffer(SceneDev sc, const uint32_t* __restrict__ pixels, uint32_t npix, uint32_t width,
+                          const float* __restrict__ hits, size_t stride, uint4* __restrict__ gbuffer, float* __restrict__ depth) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        uint32_t xy = pixels[i];
+        size_t pi = (size_t)(xy >> 16) * width + (xy & 0xFFFFu);
+        uint32_t prim = reinterpret_cast<const uint32_t*>(hits)[3 * stride + i];
+        if (prim == kMiss) {
+            depth[pi] = kBackgroundDepth;
+        } else {
+            Surface s = hit_info(sc, prim, hits[stride + i], hits[2 * stride + i]);
+            gbuffer[pi] = gbuffer_pack(s);
+            depth[pi] = hits[i];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ shading
+// wave-level queue append: one atomic per wave, order-preserving inside the wave
+__device__ __forceinline__ uint32_t wave_append(bool want, uint32_t* counter) {
+    unsigned long long mask = __ballot(want);
+    if (mask == 0ull) return 0u;
+    uint32_t lane = __lane_id();
+    uint32_t base = 0;
+    int leader = __ffsll((long long)mask) - 1;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+
+struct ShadeArgs {
+    GConstDev g;
+    SceneDev sc;
+    const uint32_t* pixels;  // x | y << 16, this rank's pixels in render order
+    uint32_t npix, width;
+    uint32_t s0;             // first sample index of this batch
+    uint32_t bounce;         // b
+    // FIRST: gbuffer images
+    const uint4* gbuffer;
+    const float* depth;
+    // !FIRST: input queue
+    const float* in_rays;
+    const float* in_hits;
+    const float* in_T;       // 3 streams + pdf stream
+    const uint32_t* in_pid;
+    const uint32_t* in_count;
+    uint32_t n_first;        // FIRST: npix * samples_in_batch
+    // outputs
+    float* out_rays;
+    float* out_T;
+    uint32_t* out_pid;
+    uint32_t* out_count;
+    float* sh_rays;
+    float* sh_contrib;
+    uint32_t* sh_pid;
+    uint32_t* sh_count;
+    float* lacc;             // 3 streams of `stride`, indexed by path id
+    size_t stride;
+};
+
+// refrence_mode.slang:28-57 for one bounce of every live path
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
+    const GConstDev& g = a.g;
+    const uint32_t flags = g.pad[0], B = g.bounces, b = a.bounce;
+    const uint32_t dims = flags ? 8u : 2u;
+    const bool nee = (flags & RT3_FLAG_NEE_SKY) && a.sc.sky != nullptr;
+    const bool bnz = (flags & RT3_FLAG_BLUENOISE) && a.sc.bluenoise != nullptr;
+    const size_t S = a.stride;
+    const uint32_t n = FIRST ? a.n_first : *a.in_count;
+    const uint32_t n_round = (n + 63u) & ~63u;  // whole waves iterate so that ballots see every lane
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
+        bool active = i < n;
+        uint32_t pid = 0;
+        V3 o = v3(0, 0, 0), d = v3(0, 0, 1), T = v3(1, 1, 1);
+        float t = 0.0f, pdf_b = 0.0f;
+        Surface surf;
+        surf.albedo = surf.emissive = v3(0, 0, 0);
+        surf.normal = v3(0, 0, 1);
+        surf.roughness = 1.0f;
+        surf.metalness = 0.0f;
+        uint32_t px = 0, py = 0;
+        if (active) {
+            pid = FIRST ? i : a.in_pid[i];
+            uint32_t xy = a.pixels[pid % a.npix];
+            px = xy & 0xFFFFu;
+            py = xy >> 16;
+        }
+        if (FIRST) {
+            if (active) {
+                size_t pi = (size_t)py * a.width + px;
+                float d0 = a.depth[pi];
+                a.lacc[pid] = 0.0f;
+                a.lacc[S + pid] = 0.0f;
+                a.lacc[2 * S + pid] = 0.0f;
+                if (d0 == kBackgroundDepth) {  // :18-21
+                    active = false;
+                } else {
+                    surf = gbuffer_unpack(a.gbuffer[pi]);  // :23
+                    primary_ray(g, px, py, o, d);          // :30
+                    t = d0;                                // :33
+                }
+            }
+        } else if (active) {
+            o = v3(a.in_rays[i], a.in_rays[S + i], a.in_rays[2 * S + i]);
+            d = v3(a.in_rays[3 * S + i], a.in_rays[4 * S + i], a.in_rays[5 * S + i]);
+            T = v3(a.in_T[i], a.in_T[S + i], a.in_T[2 * S + i]);
+            pdf_b = a.in_T[3 * S + i];
+            uint32_t prim = reinterpret_cast<const uint32_t*>(a.in_hits)[3 * S + i];
+            if (prim == kMiss) {  // :37-40 ; sky through MIS (north_star)
+                if (nee && pdf_b > 0.0f) {
+                    float su, sv;
+                    direction_to_equirect_uv(d, su, sv);
+                    V3 rad = sky_eval(a.sc, su, sv);
+                    float pl = sky_pdf(a.sc, su, sv);
+                    float w = pdf_b / (pdf_b + pl);
+                    a.lacc[pid] += T.x * (rad.x * w);
+                    a.lacc[S + pid] += T.y * (rad.y * w);
+                    a.lacc[2 * S + pid] += T.z * (rad.z * w);
+                }
+                active = false;
+            } else {
+                t = a.in_hits[i];
+                surf = hit_info(a.sc, prim, a.in_hits[S + i], a.in_hits[2 * S + i]);  // :55
+            }
+        }
+        bool emit_shadow = false, emit_ext = false;
+        V3 wl = v3(0, 1, 0), contrib = v3(0, 0, 0), nd = v3(0, 0, 1), Tn = T;
+        float pdf_n = 0.0f;
+        if (active) {
+            uint32_t seed = rng_seed(px, py, g.frame);  // :25
+            uint32_t sm = a.s0 + pid / a.npix;
+            uint32_t base = (sm * B + b) * dims;
+            float u0 = uniform_float(seed, base), u1 = uniform_float(seed, base + 1);  // :43
+            uint32_t bn = 0;
+            if (bnz) {
+                bn = *reinterpret_cast<const uint32_t*>(a.sc.bluenoise + 4 * ((size_t)(py % a.sc.bn_h) * a.sc.bn_w + (px % a.sc.bn_w)));
+                u0 = bluenoise_shift(u0, bn & 0xFFu);
+                u1 = bluenoise_shift(u1, (bn >> 8) & 0xFFu);
+            }
+            V3 N = surf.normal;
+            if ((flags & RT3_FLAG_FACEFORWARD) && dot(N, d) > 0.0f) N = neg(N);
+            V3 b1, b2;
+            build_orthonormal_basis(N, b1, b2);  // :44
+            V3 wi = diffuse_sample(u0, u1);      // :45
+            o = v3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);  // :47
+            // :50 radiance += ray_color * emissive
+            a.lacc[pid] += T.x * surf.emissive.x;
+            a.lacc[S + pid] += T.y * surf.emissive.y;
+            a.lacc[2 * S + pid] += T.z * surf.emissive.z;
+            if (nee) {
+                float ul0 = uniform_float(seed, base + 3), ul1 = uniform_float(seed, base + 4);
+                if (bnz) {
+                    ul0 = bluenoise_shift(ul0, (bn >> 16) & 0xFFu);
+                    ul1 = bluenoise_shift(ul1, (bn >> 24) & 0xFFu);
+                }
+                V3 rad;
+                float pl;
+                sky_sample(a.sc, ul0, ul1, wl, rad, pl);
+                float cosl = dot(N, wl);
+                if (cosl > 0.0f && pl > 0.0f) {
+                    float pb = cosl * kInvPi;
+                    float scale = (b == B - 1) ? (cosl * kInvPi) / pl : (cosl * kInvPi) / (pl + pb);
+                    contrib = v3((T.x * surf.albedo.x) * (rad.x * scale), (T.y * surf.albedo.y) * (rad.y * scale),
+                                 (T.z * surf.albedo.z) * (rad.z * scale));
+                    emit_shadow = true;
+                }
+            }
+            nd = basis_apply(b1, b2, N, wi);  // :48
+            pdf_n = wi.z * kInvPi;
+            Tn = T * surf.albedo;             // :51
+            emit_ext = b != B - 1;            // :53
+        }
+        if (nee) {
+            uint32_t j = wave_append(emit_shadow, a.sh_count);
+            if (emit_shadow) {
+                a.sh_rays[j] = o.x;
+                a.sh_rays[S + j] = o.y;
+                a.sh_rays[2 * S + j] = o.z;
+                a.sh_rays[3 * S + j] = wl.x;
+                a.sh_rays[4 * S + j] = wl.y;
+                a.sh_rays[5 * S + j] = wl.z;
+                a.sh_rays[6 * S + j] = kRayTMin;
+                a.sh_rays[7 * S + j] = kBackgroundDepth;
+                a.sh_contrib[j] = contrib.x;
+                a.sh_contrib[S + j] = contrib.y;
+                a.sh_contrib[2 * S + j] = contrib.z;
+                a.sh_pid[j] = pid;
+            }
+        }
+        if (b != B - 1) {
+            uint32_t j = wave_append(emit_ext, a.out_count);
+            if (emit_ext) {
+                a.out_rays[j] = o.x;
+                a.out_rays[S + j] = o.y;
+                a.out_rays[2 * S + j] = o.z;
+                a.out_rays[3 * S + j] = nd.x;
+                a.out_rays[4 * S + j] = nd.y;
+                a.out_rays[5 * S + j] = nd.z;
+                a.out_rays[6 * S + j] = kRayTMin;         // :31
+                a.out_rays[7 * S + j] = kBackgroundDepth;
+                a.out_T[j] = Tn.x;
+                a.out_T[S + j] = Tn.y;
+                a.out_T[2 * S + j] = Tn.z;
+                a.out_T[3 * S + j] = pdf_n;
+                a.out_pid[j] = pid;
+            }
+        }
+    }
+}
+
+// refrence_mode.slang:59-65 : radiance = (sum over samples, in sample order) / S, then blend with PrevLight
+__global__ void k_accumulate(GConstDev g, const uint32_t* __restrict__ pixels, uint32_t npix, uint32_t width,
+                             const float* __restrict__ depth, const float* __restrict__ lacc, size_t stride, uint32_t sb,
+                             int first_batch, int last_batch, float* __restrict__ radsum, float4* __restrict__ light,
+                             const float4* __restrict__ prev) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        uint32_t xy = pixels[i];
+        size_t pi = (size_t)(xy >> 16) * width + (xy & 0xFFFFu);
+        if (depth[pi] == kBackgroundDepth) continue;
+        float r = first_batch ? 0.0f : radsum[i], gg = first_batch ? 0.0f : radsum[npix + i], bb = first_batch ? 0.0f : radsum[2 * (size_t)npix + i];
+        for (uint32_t s = 0; s < sb; s++) {
+            size_t p = (size_t)s * npix + i;
+            r += lacc[p];
+            gg += lacc[stride + p];
+            bb += lacc[2 * stride + p];
+        }
+        if (!last_batch) {
+            radsum[i] = r;
+            radsum[npix + i] = gg;
+            radsum[2 * (size_t)npix + i] = bb;
+        } else {
+            float fs = (float)g.samples;
+            r = r / fs;
+            gg = gg / fs;
+            bb = bb / fs;
+            if (g.blendfactor >= 1.0f) {
+                light[pi] = make_float4(r, gg, bb, 0.0f);
+            } else {
+                float4 pv = prev[pi];
+                float bf = g.blendfactor;
+                light[pi] = make_float4(pv.x + (r - pv.x) * bf, pv.y + (gg - pv.y) * bf, pv.z + (bb - pv.z) * bf, 0.0f);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ postprocess
+// postprocess.slang:13-25
+__device__ __forceinline__ float agx_contrast(float x) {
+    float x2 = x * x, x4 = x2 * x2;
+    return 15.5f * x4 * x2 - 40.14f * x4 * x + 31.96f * x4 - 6.868f * x2 * x + 0.4298f * x2 + 0.1191f * x - 0.00232f;
+}
+// postprocess.slang:27-88 (AGX_LOOK 2; pow base clamped at 0)
+__device__ __forceinline__ V3 agx_tonemap(V3 c) {
+    const float m[9] = {0.842479062253094f, 0.0423282422610123f, 0.0423756549057051f, 0.0784335999999992f, 0.878468636469772f,
+                        0.0784336f, 0.0792237451477643f, 0.0791661274605434f, 0.879142973793104f};
+    const float mi[9] = {1.19687900512017f, -0.0528968517574562f, -0.0529716355144438f, -0.0980208811401368f, 1.15190312990417f,
+                         -0.0980434501171241f, -0.0990297440797205f, -0.0989611768448433f, 1.15107367264116f};
+    const float min_ev = -12.47393f, max_ev = 4.026069f;
+    float v[3], w[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) v[j] = c.x * m[j] + c.y * m[3 + j] + c.z * m[6 + j];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        float l = v[j] > 0.0f ? log2f(v[j]) : min_ev;
+        l = fmin_sel(fmax_sel(l, min_ev), max_ev);
+        l = (l - min_ev) / (max_ev - min_ev);
+        v[j] = agx_contrast(l);
+    }
+    float luma = v[0] * 0.2126f + v[1] * 0.7152f + v[2] * 0.0722f;
+#pragma unroll
+    for (int j = 0; j < 3; j++) w[j] = luma + 1.1f * (powf(fmax_sel(v[j], 0.0f), 1.1f) - luma);
+    return v3(w[0] * mi[0] + w[1] * mi[3] + w[2] * mi[6], w[0] * mi[1] + w[1] * mi[4] + w[2] * mi[7], w[0] * mi[2] + w[1] * mi[5] + w[2] * mi[8]);
+}
+// postprocess.slang:90-112
+__global__ void k_postprocess(GConstDev g, SceneDev sc, const uint32_t* __restrict__ pixels, uint32_t npix, uint32_t width,
+                              const float* __restrict__ depth, const float4* __restrict__ in, float4* __restrict__ out) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        uint32_t xy = pixels[i], px = xy & 0xFFFFu, py = xy >> 16;
+        size_t pi = (size_t)py * width + px;
+        V3 col;
+        if (depth[pi] != kBackgroundDepth) {
+            float4 c = in[pi];
+            col = v3(c.x, c.y, c.z);
+        } else {
+            V3 o, d;
+            primary_ray(g, px, py, o, d);
+            float su, sv;
+            direction_to_equirect_uv(d, su, sv);
+            col = sky_eval(sc, su, sv);
+        }
+        V3 r = agx_tonemap(col);
+        out[pi] = make_float4(r.x, r.y, r.z, 1.0f);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ tiles
+__global__ void k_pack_tiles(const uint32_t* __restrict__ pixels, uint32_t npix, uint32_t width, const float4* __restrict__ img,
+                             float4* __restrict__ dst) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        uint32_t xy = pixels[i];
+        dst[i] = img[(size_t)(xy >> 16) * width + (xy & 0xFFFFu)];
+    }
+}
+__global__ void k_unpack_tiles(const uint32_t* __restrict__ pixels, uint32_t npix, uint32_t width, const float4* __restrict__ src,
+                               float4* __restrict__ img) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        uint32_t xy = pixels[i];
+        img[(size_t)(xy >> 16) * width + (xy & 0xFFFFu)] = src[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+static inline unsigned grid_for(uint64_t n, unsigned block, unsigned max_blocks) {
+    uint64_t b = (n + block - 1) / block;
+    if (b < 1) b = 1;
+    return (unsigned)(b > max_blocks ? max_blocks : b);
+}
+
+void launch_raygen(hipStream_t st, const GConstDev& g, const uint32_t* pixels, uint32_t npix, float* rays, size_t stride) {
+    hipLaunchKernelGGL(k_raygen, dim3(grid_for(npix, 256, 4096)), dim3(256), 0, st, g, pixels, npix, rays, stride);
+}
+void launch_extend(hipStream_t st, bool count, const float4* nodes, const float4* tris, const float* rays, size_t stride,
+                   const uint32_t* count_ptr, uint32_t count_imm, uint32_t max_n, float* hits, uint32_t* cn, uint32_t* ct,
+                   unsigned long long* totals) {
+    unsigned grid = grid_for(max_n, kExtendBlock, kExtendMaxBlocks);
+    if (count)
+        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, hits, cn, ct, totals);
+    else
+        hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, hits, cn, ct, totals);
+}
+void launch_shadow(hipStream_t st, bool count, const float4* nodes, const float4* tris, const float* rays, size_t stride,
+                   const uint32_t* count_ptr, uint32_t count_imm, uint32_t max_n, const float* contrib, const uint32_t* pid, float* lacc,
+                   size_t lstride, uint32_t* occluded_out, uint32_t* cn, uint32_t* ct, unsigned long long* totals) {
+    unsigned grid = grid_for(max_n, kExtendBlock, kExtendMaxBlocks);
+    if (count)
+        hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, contrib, pid,
+                           lacc, lstride, occluded_out, cn, ct, totals);
+    else
+        hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, contrib, pid,
+                           lacc, lstride, occluded_out, cn, ct, totals);
+}
+void launch_gbuffer(hipStream_t st, const SceneDev& sc, const uint32_t* pixels, uint32_t npix, uint32_t width, const float* hits,
+                    size_t stride, void* gbuffer, float* depth) {
+    hipLaunchKernelGGL(k_gbuffer, dim3(grid_for(npix, 256, 4096)), dim3(256), 0, st, sc, pixels, npix, width, hits, stride, (uint4*)gbuffer, depth);
+}
+void launch_shade(hipStream_t st, bool first, const ShadeLaunch& L) {
+    ShadeArgs a;
+    a.g = L.g; a.sc = L.sc; a.pixels = L.pixels; a.npix = L.npix; a.width = L.width; a.s0 = L.s0; a.bounce = L.bounce;
+    a.gbuffer = (const uint4*)L.gbuffer; a.depth = L.depth;
+    a.in_rays = L.in_rays; a.in_hits = L.in_hits; a.in_T = L.in_T; a.in_pid = L.in_pid; a.in_count = L.in_count; a.n_first = L.n_first;
+    a.out_rays = L.out_rays; a.out_T = L.out_T; a.out_pid = L.out_pid; a.out_count = L.out_count;
+    a.sh_rays = L.sh_rays; a.sh_contrib = L.sh_contrib; a.sh_pid = L.sh_pid; a.sh_count = L.sh_count;
+    a.lacc = L.lacc; a.stride = L.stride;
+    unsigned grid = grid_for(L.max_n, 256, 8192);
+    if (first) hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(256), 0, st, a);
+}
+void launch_accumulate(hipStream_t st, const GConstDev& g, const uint32_t* pixels, uint32_t npix, uint32_t width, const float* depth,
+                       const float* lacc, size_t stride, uint32_t sb, int first_batch, int last_batch, float* radsum, void* light,
+                       const void* prev) {
+    hipLaunchKernelGGL(k_accumulate, dim3(grid_for(npix, 256, 8192)), dim3(256), 0, st, g, pixels, npix, width, depth, lacc, stride, sb,
+                       first_batch, last_batch, radsum, (float4*)light, (const float4*)prev);
+}
+void launch_postprocess(hipStream_t st, const GConstDev& g, const SceneDev& sc, const uint32_t* pixels, uint32_t npix, uint32_t width,
+                        const float* depth, const void* in, void* out) {
+    hipLaunchKernelGGL(k_postprocess, dim3(grid_for(npix, 256, 8192)), dim3(256), 0, st, g, sc, pixels, npix, width, depth, (const float4*)in,
+                       (float4*)out);
+}
+void launch_pack_tiles(hipStream_t st, const uint32_t* pixels, uint32_t npix, uint32_t width, const void* img, void* dst) {
+    hipLaunchKernelGGL(k_pack_tiles, dim3(grid_for(npix, 256, 8192)), dim3(256), 0, st, pixels, npix, width, (const float4*)img, (float4*)dst);
+}
+void launch_unpack_tiles(hipStream_t st, const uint32_t* pixels, uint32_t npix, uint32_t width, const void* src, void* img) {
+    hipLaunchKernelGGL(k_unpack_tiles, dim3(grid_for(npix, 256, 8192)), dim3(256), 0, st, pixels, npix, width, (const float4*)src, (float4*)img);
+}
+
+}  // namespace rt3

@@ -1,0 +1,329 @@
+// rt3_lbvh.hip -- GPU LBVH build for gfx950; stands in for create_acceleration_structure
+// (src/renderer/vulkan/raytracing.rs:88-148, flags PREFER_FAST_TRACE :103,131) which hands the job to the Vulkan driver.
+//
+//   k_prim_bounds  triangle boxes + scene / centroid bounds (wave reduce, ordered-uint atomics)
+//   k_morton       63-bit Morton code of the box centre (21 bits per axis)
+//   hipcub radix sort of (code, primitive) pairs, 64-bit keys, stable -> ties keep primitive order
+//   k_leaves       Morton-ordered triangle records {v0,e1,e2,prim} (48 B) + padded leaf boxes
+//   k_hierarchy    Karras 2012 radix-tree topology, one thread per internal node
+//   k_refit        bottom-up boxes: the second thread to arrive at a node (agent-scope atomic + fences) fills the
+//                  64 B traversal node {child0 box, child1 box, child refs} and climbs on
+//   k_depth        tree depth (host checks it against the traversal stack)
+// min/max are exact, so the tree is a pure function of the input and is compared bit for bit with the CPU oracle.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include "rt3_device.hpp"
+#include "rt3_internal.hpp"
+
+namespace rt3 {
+
+__device__ __forceinline__ uint32_t float_to_ordered(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_to_float(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
+
+__device__ __forceinline__ void fetch_triangle(const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,
+                                               const uint32_t* first_prim, uint32_t prim, V3& a, V3& b, V3& c) {
+    uint32_t g = prim_geom[prim];
+    const GeometryInfoDev& gi = geoms[g];
+    uint32_t io = gi.index_offset + 3u * (prim - first_prim[g]);
+    const float* v0 = verts + 8 * (size_t)(gi.vertex_offset + indices[io]);
+    const float* v1 = verts + 8 * (size_t)(gi.vertex_offset + indices[io + 1]);
+    const float* v2 = verts + 8 * (size_t)(gi.vertex_offset + indices[io + 2]);
+    a = v3(v0[0], v0[1], v0[2]);
+    b = v3(v1[0], v1[1], v1[2]);
+    c = v3(v2[0], v2[1], v2[2]);
+}
+
+// bounds[0..2] scene min, [3..5] scene max, [6..8] centroid min, [9..11] centroid max (ordered-uint encoded)
+__global__ void k_prim_bounds(const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,
+                              const uint32_t* first_prim, uint32_t n, float* bmin, float* bmax, uint32_t* bounds) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        V3 a, b, c;
+        fetch_triangle(verts, indices, geoms, prim_geom, first_prim, i, a, b, c);
+        float mn[3] = {fmin_sel(a.x, fmin_sel(b.x, c.x)), fmin_sel(a.y, fmin_sel(b.y, c.y)), fmin_sel(a.z, fmin_sel(b.z, c.z))};
+        float mx[3] = {fmax_sel(a.x, fmax_sel(b.x, c.x)), fmax_sel(a.y, fmax_sel(b.y, c.y)), fmax_sel(a.z, fmax_sel(b.z, c.z))};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            bmin[3 * (size_t)i + k] = mn[k];
+            bmax[3 * (size_t)i + k] = mx[k];
+            float ce = (mn[k] + mx[k]) * 0.5f;
+            lo[k] = fmin_sel(lo[k], mn[k]);
+            hi[k] = fmax_sel(hi[k], mx[k]);
+            clo[k] = fmin_sel(clo[k], ce);
+            chi[k] = fmax_sel(chi[k], ce);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[k] = fmin_sel(lo[k], __shfl_xor(lo[k], off));
+            hi[k] = fmax_sel(hi[k], __shfl_xor(hi[k], off));
+            clo[k] = fmin_sel(clo[k], __shfl_xor(clo[k], off));
+            chi[k] = fmax_sel(chi[k], __shfl_xor(chi[k], off));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            atomicMin(&bounds[k], float_to_ordered(lo[k]));
+            atomicMax(&bounds[3 + k], float_to_ordered(hi[k]));
+            atomicMin(&bounds[6 + k], float_to_ordered(clo[k]));
+            atomicMax(&bounds[9 + k], float_to_ordered(chi[k]));
+        }
+    }
+}
+
+__device__ __forceinline__ uint64_t expand21(uint32_t v) {
+    uint64_t x = v & 0x1FFFFFu;
+    x = (x | (x << 32)) & 0x001F00000000FFFFull;
+    x = (x | (x << 16)) & 0x001F0000FF0000FFull;
+    x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+    x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+
+__global__ void k_morton(const float* bmin, const float* bmax, const uint32_t* bounds, uint32_t n, uint64_t* keys, uint32_t* vals) {
+    float cmin[3], cext[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        cmin[k] = ordered_to_float(bounds[6 + k]);
+        cext[k] = ordered_to_float(bounds[9 + k]) - cmin[k];
+    }
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint32_t q[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float ce = (bmin[3 * (size_t)i + k] + bmax[3 * (size_t)i + k]) * 0.5f;
+            float nrm = cext[k] > 0.0f ? (ce - cmin[k]) / cext[k] : 0.0f;
+            q[k] = (uint32_t)fmin_sel(nrm * 2097152.0f, 2097151.0f);
+        }
+        keys[i] = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
+        vals[i] = i;
+    }
+}
+
+__global__ void k_leaves(const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,
+                         const uint32_t* first_prim, const uint32_t* sorted_prim, const float* bmin, const float* bmax,
+                         const uint32_t* bounds, uint32_t n, float4* tris, float* lmin, float* lmax) {
+    float ex = ordered_to_float(bounds[3]) - ordered_to_float(bounds[0]);
+    float ey = ordered_to_float(bounds[4]) - ordered_to_float(bounds[1]);
+    float ez = ordered_to_float(bounds[5]) - ordered_to_float(bounds[2]);
+    float pad = fmax_sel(ex, fmax_sel(ey, ez)) * 1.0e-5f;  // conservative leaf padding
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        uint32_t p = sorted_prim[k];
+        V3 a, b, c;
+        fetch_triangle(verts, indices, geoms, prim_geom, first_prim, p, a, b, c);
+        V3 e1 = b - a, e2 = c - a;
+        tris[3 * (size_t)k + 0] = make_float4(a.x, a.y, a.z, e1.x);
+        tris[3 * (size_t)k + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
+        tris[3 * (size_t)k + 2] = make_float4(e2.z, __uint_as_float(p), 0.0f, 0.0f);
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            lmin[3 * (size_t)k + j] = bmin[3 * (size_t)p + j] - pad;
+            lmax[3 * (size_t)k + j] = bmax[3 * (size_t)p + j] + pad;
+        }
+    }
+}
+
+__device__ __forceinline__ int delta(const uint64_t* codes, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    uint64_t a = codes[i], b = codes[j];
+    if (a != b) return __clzll((long long)(a ^ b));
+    return 64 + __clz((int)((uint32_t)i ^ (uint32_t)j));
+}
+
+// Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees", HPG 2012, section 4
+__global__ void k_hierarchy(const uint64_t* codes, int n, uint32_t* left, uint32_t* right, uint32_t* parent_internal, uint32_t* parent_leaf) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n - 1; i += gridDim.x * blockDim.x) {
+        int d = (delta(codes, n, i, i + 1) - delta(codes, n, i, i - 1)) >= 0 ? 1 : -1;
+        int dmin = delta(codes, n, i, i - d);
+        int lmax = 2;
+        while (delta(codes, n, i, i + lmax * d) > dmin) lmax *= 2;
+        int l = 0;
+        for (int t = lmax / 2; t >= 1; t /= 2)
+            if (delta(codes, n, i, i + (l + t) * d) > dmin) l += t;
+        int j = i + l * d;
+        int dnode = delta(codes, n, i, j);
+        int s = 0, t = l;
+        do {
+            t = (t + 1) >> 1;
+            if (delta(codes, n, i, i + (s + t) * d) > dnode) s += t;
+        } while (t > 1);
+        int gamma = i + s * d + (d < 0 ? d : 0);
+        int lo = i < j ? i : j, hi = i < j ? j : i;
+        if (lo == gamma) {
+            left[i] = 0x80000000u | (uint32_t)gamma;
+            parent_leaf[gamma] = (uint32_t)i;
+        } else {
+            left[i] = (uint32_t)gamma;
+            parent_internal[gamma] = (uint32_t)i;
+        }
+        if (hi == gamma + 1) {
+            right[i] = 0x80000000u | (uint32_t)(gamma + 1);
+            parent_leaf[gamma + 1] = (uint32_t)i;
+        } else {
+            right[i] = (uint32_t)(gamma + 1);
+            parent_internal[gamma + 1] = (uint32_t)i;
+        }
+        if (i == 0) parent_internal[0] = 0xFFFFFFFFu;
+    }
+}
+
+// bottom-up refit.  nbox holds each internal node's own box (6 floats).  Inter-workgroup hand-off of a child's box goes
+// through an agent-scope fence + returning atomic on the node's arrival counter, then an agent-scope fence on the
+// consumer before it reads (per-XCD L2s are not coherent).
+__global__ void k_refit(const uint32_t* left, const uint32_t* right, const uint32_t* parent_internal, const uint32_t* parent_leaf,
+                        const float* lmin, const float* lmax, uint32_t n, float* nbox, uint32_t* arrive, float4* nodes) {
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        uint32_t cur = parent_leaf[k];
+        while (cur != 0xFFFFFFFFu) {
+            __threadfence();
+            uint32_t prev = atomicAdd(&arrive[cur], 1u);
+            if (prev == 0u) break;  // first arrival: the sibling subtree is not finished yet
+            __threadfence();
+            uint32_t ch[2] = {left[cur], right[cur]};
+            float mn[2][3], mx[2][3];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                if (ch[c] & 0x80000000u) {
+                    uint32_t q = ch[c] & 0x7FFFFFFFu;
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        mn[c][j] = lmin[3 * (size_t)q + j];
+                        mx[c][j] = lmax[3 * (size_t)q + j];
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 3; j++) {
+                        mn[c][j] = __hip_atomic_load(&nbox[6 * (size_t)ch[c] + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        mx[c][j] = __hip_atomic_load(&nbox[6 * (size_t)ch[c] + 3 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+            }
+            nodes[4 * (size_t)cur + 0] = make_float4(mn[0][0], mn[0][1], mn[0][2], mx[0][0]);
+            nodes[4 * (size_t)cur + 1] = make_float4(mx[0][1], mx[0][2], mn[1][0], mn[1][1]);
+            nodes[4 * (size_t)cur + 2] = make_float4(mn[1][2], mx[1][0], mx[1][1], mx[1][2]);
+            nodes[4 * (size_t)cur + 3] = make_float4(__uint_as_float(ch[0]), __uint_as_float(ch[1]), 0.0f, 0.0f);
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                __hip_atomic_store(&nbox[6 * (size_t)cur + j], fmin_sel(mn[0][j], mn[1][j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&nbox[6 * (size_t)cur + 3 + j], fmax_sel(mx[0][j], mx[1][j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            cur = parent_internal[cur];
+        }
+    }
+}
+
+__global__ void k_depth(const uint32_t* parent_internal, const uint32_t* parent_leaf, uint32_t n, uint32_t* max_depth) {
+    uint32_t best = 0;
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
+        uint32_t d = 1, cur = parent_leaf[k];
+        while (cur != 0xFFFFFFFFu) {
+            d++;
+            cur = parent_internal[cur];
+        }
+        best = d > best ? d : best;
+    }
+    if (best) atomicMax(max_depth, best);
+}
+
+// single-triangle scene: root with child0 = the leaf and an empty child1 box
+__global__ void k_single(const float* lmin, const float* lmax, float4* nodes) {
+    nodes[0] = make_float4(lmin[0], lmin[1], lmin[2], lmax[0]);
+    nodes[1] = make_float4(lmax[1], lmax[2], INFINITY, INFINITY);
+    nodes[2] = make_float4(INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    nodes[3] = make_float4(__uint_as_float(0x80000000u), __uint_as_float(0x80000000u), 0.0f, 0.0f);
+}
+
+#define LB_CHECK(x)                  \
+    do {                             \
+        hipError_t e_ = (x);         \
+        if (e_ != hipSuccess) {      \
+            err = e_;                \
+            goto done;               \
+        }                            \
+    } while (0)
+
+hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,
+                      const uint32_t* first_prim, uint32_t n, LbvhResult* out) {
+    hipError_t err = hipSuccess;
+    *out = LbvhResult{};
+    out->n_tris = n;
+    if (n == 0) return hipSuccess;
+    const uint32_t nn = n > 1 ? n - 1 : 1;
+    float *bmin = nullptr, *bmax = nullptr, *lmin = nullptr, *lmax = nullptr, *nbox = nullptr;
+    uint32_t *bounds = nullptr, *vals_in = nullptr, *vals_out = nullptr, *left = nullptr, *right = nullptr, *pint = nullptr, *pleaf = nullptr,
+             *arrive = nullptr, *depth = nullptr;
+    uint64_t *keys_in = nullptr, *keys_out = nullptr;
+    void* temp = nullptr;
+    size_t temp_bytes = 0;
+    const unsigned grid = (unsigned)(((uint64_t)n + 255) / 256 > 4096 ? 4096 : ((uint64_t)n + 255) / 256);
+    uint32_t init_bounds[12];
+    for (int k = 0; k < 3; k++) {
+        init_bounds[k] = 0xFFFFFFFFu;
+        init_bounds[3 + k] = 0u;
+        init_bounds[6 + k] = 0xFFFFFFFFu;
+        init_bounds[9 + k] = 0u;
+    }
+    LB_CHECK(hipMalloc(&bmin, (size_t)n * 12));
+    LB_CHECK(hipMalloc(&bmax, (size_t)n * 12));
+    LB_CHECK(hipMalloc(&lmin, (size_t)n * 12));
+    LB_CHECK(hipMalloc(&lmax, (size_t)n * 12));
+    LB_CHECK(hipMalloc(&nbox, (size_t)nn * 24));
+    LB_CHECK(hipMalloc(&bounds, 64));
+    LB_CHECK(hipMalloc(&keys_in, (size_t)n * 8));
+    LB_CHECK(hipMalloc(&keys_out, (size_t)n * 8));
+    LB_CHECK(hipMalloc(&vals_in, (size_t)n * 4));
+    LB_CHECK(hipMalloc(&vals_out, (size_t)n * 4));
+    LB_CHECK(hipMalloc(&left, (size_t)nn * 4));
+    LB_CHECK(hipMalloc(&right, (size_t)nn * 4));
+    LB_CHECK(hipMalloc(&pint, (size_t)nn * 4));
+    LB_CHECK(hipMalloc(&pleaf, (size_t)n * 4));
+    LB_CHECK(hipMalloc(&arrive, (size_t)nn * 4));
+    LB_CHECK(hipMalloc(&depth, 4));
+    LB_CHECK(hipMalloc(&out->nodes, (size_t)nn * 64));
+    LB_CHECK(hipMalloc(&out->tris, (size_t)n * 48));
+    out->n_nodes = nn;
+    LB_CHECK(hipMemcpyAsync(bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, st));
+    LB_CHECK(hipMemsetAsync(arrive, 0, (size_t)nn * 4, st));
+    LB_CHECK(hipMemsetAsync(depth, 0, 4, st));
+    LB_CHECK(hipMemsetAsync(out->nodes, 0, (size_t)nn * 64, st));
+    hipLaunchKernelGGL(k_prim_bounds, dim3(grid), dim3(256), 0, st, verts, indices, geoms, prim_geom, first_prim, n, bmin, bmax, bounds);
+    hipLaunchKernelGGL(k_morton, dim3(grid), dim3(256), 0, st, bmin, bmax, bounds, n, keys_in, vals_in);
+    LB_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, 63, st));
+    LB_CHECK(hipMalloc(&temp, temp_bytes ? temp_bytes : 16));
+    LB_CHECK(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, 63, st));
+    hipLaunchKernelGGL(k_leaves, dim3(grid), dim3(256), 0, st, verts, indices, geoms, prim_geom, first_prim, vals_out, bmin, bmax, bounds, n,
+                       out->tris, lmin, lmax);
+    if (n == 1) {
+        hipLaunchKernelGGL(k_single, dim3(1), dim3(1), 0, st, lmin, lmax, out->nodes);
+        out->max_depth = 1;
+    } else {
+        hipLaunchKernelGGL(k_hierarchy, dim3(grid), dim3(256), 0, st, keys_out, (int)n, left, right, pint, pleaf);
+        hipLaunchKernelGGL(k_refit, dim3(grid), dim3(256), 0, st, left, right, pint, pleaf, lmin, lmax, n, nbox, arrive, out->nodes);
+        hipLaunchKernelGGL(k_depth, dim3(grid), dim3(256), 0, st, pint, pleaf, n, depth);
+        LB_CHECK(hipMemcpyAsync(&out->max_depth, depth, 4, hipMemcpyDeviceToHost, st));
+    }
+    LB_CHECK(hipGetLastError());
+    LB_CHECK(hipStreamSynchronize(st));
+done:
+    for (void* p : {(void*)bmin, (void*)bmax, (void*)lmin, (void*)lmax, (void*)nbox, (void*)bounds, (void*)keys_in, (void*)keys_out, (void*)vals_in,
+                    (void*)vals_out, (void*)left, (void*)right, (void*)pint, (void*)pleaf, (void*)arrive, (void*)depth, temp})
+        (void)hipFree(p);
+    if (err != hipSuccess) {
+        (void)hipFree(out->nodes);
+        (void)hipFree(out->tris);
+        out->nodes = nullptr;
+        out->tris = nullptr;
+    }
+    return err;
+}
+
+}  // namespace rt3

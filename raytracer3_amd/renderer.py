@@ -1,0 +1,144 @@
+"""Frame description: the path-tracing counterpart of `renderer::commands` (src/renderer/mod.rs:65-106) and of the
+`Camera` component (src/components/camera.rs:23-59), plus the tile-partitioned multi-GPU frame (north_star).
+
+Per frame, three passes exactly as the old shaders were wired:
+  RayTracingPass("gbuffer")        -> packed G-buffer + depth                 shaders/old/gbuffer.slang
+  RayTracingPass("refrence_mode")  -> Light (RGBA32F linear radiance)          shaders/old/refrence_mode.slang
+  ComputePass("postprocess")       -> display image (AgX)                      shaders/old/postprocess.slang
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib as L
+from .render_graph import IMPORTED, ComputePass, Context, DispatchSize, ImageSize, RayTracingPass, RenderGraph, WorkSize2D
+
+DEFAULT_FLAGS = L.F_NEE_SKY | L.F_BLUENOISE | L.F_FACEFORWARD
+
+
+class Camera:
+    """components/camera.rs:23-59.  `fov` in radians, like the reference (`65.0_f32.to_radians()`, main.rs:72)."""
+
+    def __init__(self, position, direction, fov, aspect_ratio, z_near=0.1, z_far=1000.0):
+        d = np.asarray(direction, np.float32)
+        self.position = np.asarray(position, np.float32)
+        self.direction = d / np.float32(np.linalg.norm(d))  # Camera::new normalises, camera.rs:43
+        self.fov, self.aspect_ratio, self.z_near, self.z_far = float(np.float32(fov)), float(np.float32(aspect_ratio)), z_near, z_far
+
+    def gconst(self, window) -> L.GConst:
+        """view_matrix / projection_matrix (camera.rs:52-58) + the GConst fill of renderer/mod.rs:72-78."""
+        g = L.GConst()
+        p = (C.c_float * 3)(*[float(x) for x in self.position])
+        d = (C.c_float * 3)(*[float(x) for x in self.direction])
+        L.load().rt3_camera_gconst(p, d, self.fov, self.aspect_ratio, self.z_near, self.z_far, float(window[0]), float(window[1]), C.byref(g))
+        return g
+
+    def view_matrix(self, window=(1, 1)):
+        return np.array(self.gconst(window).view[:], np.float32).reshape(4, 4).T
+
+    def projection_matrix(self, window=(1, 1)):
+        return np.array(self.gconst(window).proj[:], np.float32).reshape(4, 4).T
+
+
+class PathTracer:
+    """One GPU's share of the frame.  `rank` / `n_ranks` select the interleaved 64x64 tiles this process renders."""
+
+    def __init__(self, window, device=0, rank=0, n_ranks=1):
+        self.window = (int(window[0]), int(window[1]))
+        self.ctx = Context(device)
+        self.rank, self.n_ranks = rank, n_ranks
+        self.ctx.set_tile_partition(self.window[0], self.window[1], rank, n_ranks)
+        self.rg = RenderGraph(self.ctx, self.window)
+        self._accel = None
+
+    def close(self):
+        self.ctx.close()
+
+    def set_scene(self, mesh, sky=None, bluenoise=None):
+        self.ctx.upload_mesh(mesh)
+        if sky is not None:
+            self.ctx.set_sky(sky)
+        if bluenoise is not None:
+            self.ctx.set_bluenoise(bluenoise)
+        self._accel = self.ctx.build_accel()
+
+    def make_gconst(self, camera: Camera, samples, bounces=4, frame=0, blendfactor=1.0, flags=DEFAULT_FLAGS) -> L.GConst:
+        g = camera.gconst(self.window)
+        g.frame, g.samples, g.bounces, g.blendfactor = frame, samples, bounces, blendfactor
+        g.pad[0] = flags
+        return g
+
+    def commands(self, gconst: L.GConst, postprocess=True):
+        """Build this frame's nodes (the analogue of renderer::commands, renderer/mod.rs:65-106)."""
+        rg = self.rg
+        rg.begin_frame()
+        gbuffer = rg.image(ImageSize.FullScreen, L.FORMAT_R32G32B32A32_UINT, "gbuffer")
+        depth = rg.image(ImageSize.FullScreen, L.FORMAT_R32_SFLOAT, "gbuffer_depth")
+        light = rg.image(ImageSize.FullScreen, L.FORMAT_R32G32B32A32_SFLOAT, "Light")
+        prev = rg.image(ImageSize.FullScreen, L.FORMAT_R32G32B32A32_SFLOAT, "PrevLight")
+        out = rg.image(ImageSize.FullScreen, L.FORMAT_R32G32B32A32_SFLOAT, "color")
+        gb = (RayTracingPass.new(rg, "gbuffer").shader("gbuffer").constants(gconst)
+              .write(IMPORTED, gbuffer).write(IMPORTED, depth).launch(WorkSize2D.FullScreen))
+        pt = (RayTracingPass.new(rg, "refrence_mode").shader("refrence_mode").constants(gconst)
+              .read(gb, gbuffer).read(gb, depth).write(IMPORTED, light).read(IMPORTED, prev).launch(WorkSize2D.FullScreen))
+        if postprocess:
+            (ComputePass.new(rg, "postprocess").shader("postprocess").constants(gconst)
+             .read(gb, depth).write(IMPORTED, out).read(pt, light).dispatch(DispatchSize.FullScreen))
+        self.handles = dict(gbuffer=gbuffer, depth=depth, light=light, prev=prev, color=out)
+        return self.handles
+
+    def render(self, gconst, postprocess=False, wait=True):
+        h = self.commands(gconst, postprocess)
+        self.rg.draw_frame(h["color"] if postprocess else h["light"], wait=wait)
+        return h
+
+    # ---- results
+    def light(self):
+        W, H = self.window
+        return self.rg.download(self.handles["light"], (H, W, 4), np.float32)
+
+    def color(self):
+        W, H = self.window
+        return self.rg.download(self.handles["color"], (H, W, 4), np.float32)
+
+    def gbuffer(self):
+        W, H = self.window
+        return self.rg.download(self.handles["gbuffer"], (H, W, 4), np.uint32), self.rg.download(self.handles["depth"], (H, W), np.float32)
+
+    def copy_light_to_prev(self):
+        """Progressive accumulation: PrevLight <- Light (refrence_mode.slang:11,61-65)."""
+        self.rg.upload(self.handles["prev"], self.light())
+
+    # ---- multi-GPU: one gather of the per-rank tile buffers at frame end (torch.distributed, backend nccl == RCCL)
+    def tile_pixel_count(self, rank):
+        return self.ctx.tile_pixel_count(rank, self.n_ranks)
+
+    def gather_light(self, dist=None, torch=None, dst=0):
+        """Pack this rank's tiles of `Light`, gather them on `dst` with ONE collective and untile there.
+        Returns the full (H, W, 4) image on `dst` (None elsewhere).  With n_ranks == 1 no collective is issued."""
+        W, H = self.window
+        if self.n_ranks == 1:
+            return self.light()
+        counts = [self.tile_pixel_count(r) for r in range(self.n_ranks)]
+        cap = max(counts)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        mine = torch.zeros((cap, 4), dtype=torch.float32, device=dev)
+        self.ctx.check(self.ctx.lib.rt3_image_pack_tiles(self.ctx.h, self.handles["light"], self.rank, self.n_ranks, C.c_void_p(mine.data_ptr())))
+        self.ctx.wait()
+        if self.rank == dst:
+            parts = [torch.empty_like(mine) for _ in range(self.n_ranks)]
+            dist.gather(mine, parts, dst=dst)
+            torch.cuda.synchronize()
+            for r, p in enumerate(parts):
+                self.ctx.check(self.ctx.lib.rt3_image_unpack_tiles(self.ctx.h, self.handles["light"], r, self.n_ranks, C.c_void_p(p.data_ptr())))
+            self.ctx.wait()
+            return self.light()
+        dist.gather(mine, None, dst=dst)
+        return None
+
+
+def default_camera(window, position, direction, fov_deg):
+    return Camera(position, direction, math.radians(fov_deg), window[0] / window[1])

@@ -1,0 +1,309 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars: bit-exact for integer / index / packed data (BVH arrays, hits, traversal counts, G-buffer); linear radiance is
+expected bit-exact too (arithmetic contract) and must at least meet the north_star bar RMSE <= 1e-3;
+the display transform (log2/pow from libm vs device) is compared with tolerance 2e-5."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import orc
+from raytracer3_amd import _lib as L
+from raytracer3_amd import assets, scenes
+from raytracer3_amd.renderer import Camera, PathTracer
+from raytracer3_amd.render_graph import Context
+
+pytestmark = pytest.mark.gpu
+
+FULL = L.F_NEE_SKY | L.F_BLUENOISE | L.F_FACEFORWARD
+
+
+def as_orc(g: L.GConst) -> orc.GConst:
+    o = orc.GConst()
+    C.memmove(C.byref(o), C.byref(g), 304)
+    return o
+
+
+@pytest.fixture(scope="module")
+def small():
+    mesh = scenes.atrium(0.3)
+    sky = scenes.sky(512, 256)
+    bn = assets.load_bluenoise()
+    return mesh, sky, bn, orc.Scene(mesh, sky, bn)
+
+
+@pytest.fixture(scope="module")
+def cornell():
+    mesh = scenes.cornell()
+    return mesh, orc.Scene(mesh)
+
+
+def rays_random(n, seed, lo, hi):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(lo, hi, (n, 3)).T
+    d = rng.normal(size=(3, n))
+    d /= np.linalg.norm(d, axis=0)
+    return np.concatenate([o, d, np.full((1, n), 0.001), np.full((1, n), 1e5)]).astype(np.float32)
+
+
+def test_device_is_gfx950():
+    ctx = Context(0)
+    assert "gfx950" in ctx.device_name
+    ctx.close()
+
+
+def test_lbvh_bit_identical_to_oracle(small):
+    mesh, sky, bn, osc = small
+    ctx = Context(0)
+    ctx.upload_mesh(mesh)
+    handle = ctx.build_accel()
+    assert handle >> 30 == L.TAG_ACCEL
+    nn, nt, depth = ctx.accel_info()
+    assert (nn, nt, depth) == (osc.n_nodes, osc.n_tris, osc.max_depth)
+    nodes, tris = ctx.accel_download()
+    assert np.array_equal(tris, osc.tris())
+    assert np.array_equal(nodes[:, :14], osc.nodes()[:, :14])
+    ctx.close()
+
+
+def test_lbvh_edge_cases():
+    """empty scene, one triangle, duplicate triangles (identical Morton codes)."""
+    ctx = Context(0)
+    mb = assets.MeshBuilder()
+    tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32)
+    nrm = np.tile([0, 0, 1], (3, 1))
+    mb.add("one", tri, nrm, None, [[0, 1, 2]], assets.Material())
+    one = mb.build()
+    ctx.upload_mesh(one)
+    ctx.build_accel()
+    o1 = orc.Scene(one)
+    rays = np.array([[0.2, 0.2, 1, 0, 0, -1, 0, 1e5], [2, 2, 1, 0, 0, -1, 0, 1e5]], np.float32).T.copy()
+    t, u, v, p, _ = ctx.trace_rays(rays)
+    ot, ou, ov, op = o1.trace_closest(rays)
+    assert np.array_equal(p, op) and p[0] == 0 and p[1] == L.MISS and t[0] == ot[0] == 1.0
+    # 5 coincident copies: equal t -> lowest primitive id wins, on both sides
+    mb = assets.MeshBuilder()
+    for k in range(5):
+        mb.add(f"c{k}", tri, nrm, None, [[0, 1, 2]], assets.Material())
+    dup = mb.build()
+    ctx.upload_mesh(dup)
+    ctx.build_accel()
+    od = orc.Scene(dup)
+    nodes, tris = ctx.accel_download()
+    assert np.array_equal(tris, od.tris()) and np.array_equal(nodes[:, :14], od.nodes()[:, :14])
+    t, u, v, p, _ = ctx.trace_rays(rays)
+    assert p[0] == 0 and p[1] == L.MISS
+    # empty scene: everything misses, passes are no-ops
+    mb = assets.MeshBuilder()
+    mb.add("none", np.zeros((0, 3)), np.zeros((0, 3)), None, np.zeros((0, 3), np.uint32), assets.Material())
+    ctx.upload_mesh(mb.build())
+    ctx.build_accel()
+    t, u, v, p, _ = ctx.trace_rays(rays)
+    assert (p == L.MISS).all()
+    ctx.close()
+
+
+def test_trace_closest_and_any_exact(small):
+    mesh, sky, bn, osc = small
+    ctx = Context(0)
+    ctx.upload_mesh(mesh)
+    ctx.build_accel()
+    W, H = 192, 108
+    cam = Camera((-10, 2, 0), (1, 0.1, 0), math.radians(65.0), W / H)
+    g = as_orc(cam.gconst((W, H)))
+    ys, xs = np.mgrid[0:H, 0:W]
+    prim_rays = orc.primary_rays(g, xs.ravel(), ys.ravel())
+    rnd = rays_random(50000, 1, [-14, 0.2, -8], [14, 12, 8])
+    for rays in (prim_rays, rnd):
+        t, u, v, p, cn, ct, _ = ctx.trace_rays(rays, counts=True)
+        ot, ou, ov, op, ocn, oct = osc.trace_closest(rays, counts=True)
+        assert np.array_equal(p, op)
+        hit = p != L.MISS
+        assert np.array_equal(t[hit].view(np.uint32), ot[hit].view(np.uint32))
+        assert np.array_equal(u[hit].view(np.uint32), ou[hit].view(np.uint32))
+        assert np.array_equal(v[hit].view(np.uint32), ov[hit].view(np.uint32))
+        assert np.array_equal(cn, ocn) and np.array_equal(ct, oct)  # same traversal order -> same algorithmic bytes
+        # without counting: same hits
+        t2, u2, v2, p2, _ = ctx.trace_rays(rays)
+        assert np.array_equal(p2, p) and np.array_equal(t2.view(np.uint32), t.view(np.uint32))
+        occ = ctx.trace_rays(rays, any_hit=True)[3]
+        assert np.array_equal(occ != 0, osc.trace_any(rays) != 0)
+    # pinned against the brute-force fp32 intersector on a subset
+    sub = rnd[:, :3000]
+    bt, bu, bv, bp = osc.trace_brute(sub, 0)
+    t, u, v, p, _ = ctx.trace_rays(sub)
+    assert np.array_equal(p, bp) and np.array_equal(t[p != L.MISS], bt[p != L.MISS])
+    ctx.close()
+
+
+def render_both(mesh, sky, bn, osc, W, H, cam_kw, samples, bounces, flags, frame=0, batch_spp=0, rank=0, n_ranks=1):
+    pt = PathTracer((W, H), rank=rank, n_ranks=n_ranks)
+    pt.set_scene(mesh, sky, bn)
+    if batch_spp:
+        pt.ctx.set_option(L.OPT_BATCH_SPP, batch_spp)
+    cam = Camera(cam_kw["position"], cam_kw["direction"], math.radians(cam_kw["fov_deg"]), W / H)
+    g = pt.make_gconst(cam, samples, bounces, frame=frame, flags=flags)
+    pt.render(g, postprocess=True)
+    light = pt.light()
+    gb, depth = pt.gbuffer()
+    color = pt.color()
+    st = pt.ctx.stats()
+    pt.close()
+    return g, light, gb, depth, color, st
+
+
+@pytest.mark.parametrize("flags", [0, FULL])
+def test_frame_parity_atrium(small, flags):
+    mesh, sky, bn, osc = small
+    W, H = 160, 90
+    g, light, gb, depth, color, st = render_both(mesh, sky, bn, osc, W, H, scenes.ATRIUM_CAMERA, 8, 4, flags, frame=3)
+    og = as_orc(g)
+    ogb, odepth = osc.gbuffer(og)
+    assert np.array_equal(depth.view(np.uint32), odepth.view(np.uint32))
+    hit = depth != L.BACKGROUND_DEPTH
+    assert hit.mean() > 0.5
+    assert np.array_equal(gb[hit], ogb[hit])
+    olight, counts = osc.reference_mode(og, ogb, odepth)
+    diff = light[..., :3].astype(np.float64) - olight[..., :3]
+    rmse = float(np.sqrt(np.mean(diff**2)))
+    assert rmse <= 1e-3, rmse  # north_star bar
+    assert np.array_equal(light.view(np.uint32), olight.view(np.uint32)), f"max abs diff {np.abs(diff).max()}"
+    # ray accounting: primary rays + bounce rays, shadow rays
+    assert st.extension_rays == W * H + int(counts[0])
+    assert st.shadow_rays == int(counts[1])
+    # display transform: libm log2f/powf vs device -> tolerance
+    ocolor = osc.postprocess(og, odepth, olight)
+    assert np.allclose(color, ocolor, atol=2e-5, rtol=1e-4)
+
+
+def test_frame_parity_cornell_reference_semantics(cornell):
+    """Closed scene: no path ever misses, so the RNG counters coincide with the reference's sequential index++."""
+    mesh, osc = cornell
+    W, H = 128, 128
+    g, light, gb, depth, color, st = render_both(mesh, None, None, osc, W, H, scenes.CORNELL_CAMERA, 16, 4, 0, frame=11)
+    og = as_orc(g)
+    ogb, odepth = osc.gbuffer(og)
+    assert (depth != L.BACKGROUND_DEPTH).all()
+    assert np.array_equal(gb, ogb) and np.array_equal(depth, odepth)
+    olight, counts = osc.reference_mode(og, ogb, odepth)
+    assert np.array_equal(light.view(np.uint32), olight.view(np.uint32))
+    assert light[..., :3].mean() > 0.01
+    assert st.extension_rays == W * H + W * H * 16 * 3  # nothing escapes a closed box
+
+
+def test_batching_and_blend_do_not_change_the_image(small):
+    mesh, sky, bn, osc = small
+    W, H = 96, 54
+    a = render_both(mesh, sky, bn, osc, W, H, scenes.ATRIUM_CAMERA, 8, 3, FULL, batch_spp=0)[1]
+    b = render_both(mesh, sky, bn, osc, W, H, scenes.ATRIUM_CAMERA, 8, 3, FULL, batch_spp=3)[1]  # ragged batches 3+3+2
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_progressive_blend_matches_oracle(small):
+    mesh, sky, bn, osc = small
+    W, H = 64, 36
+    pt = PathTracer((W, H))
+    pt.set_scene(mesh, sky, bn)
+    cam = Camera(scenes.ATRIUM_CAMERA["position"], scenes.ATRIUM_CAMERA["direction"], math.radians(65.0), W / H)
+    prev = None
+    for frame in range(3):
+        g = pt.make_gconst(cam, 2, 3, frame=frame, blendfactor=1.0 / (frame + 1), flags=FULL)
+        pt.render(g)
+        light = pt.light()
+        og = as_orc(g)
+        if frame == 0:
+            ogb, odepth = osc.gbuffer(og)
+        olight, _ = osc.reference_mode(og, ogb, odepth, prev=prev)
+        assert np.array_equal(light.view(np.uint32), olight.view(np.uint32))
+        prev = olight
+        pt.copy_light_to_prev()
+    pt.close()
+
+
+def test_tile_partition_is_bit_identical(small):
+    """the image must not depend on the GPU count (RNG is seeded by global pixel coordinates)."""
+    mesh, sky, bn, osc = small
+    W, H = 200, 150  # ragged: 4 x 3 tiles, partial right / bottom tiles
+    full = render_both(mesh, sky, bn, osc, W, H, scenes.ATRIUM_CAMERA, 4, 3, FULL)[1]
+    acc = np.zeros_like(full)
+    owned = np.zeros((H, W), np.int32)
+    for r in range(3):
+        part = render_both(mesh, sky, bn, osc, W, H, scenes.ATRIUM_CAMERA, 4, 3, FULL, rank=r, n_ranks=3)[1]
+        xy = orc.tile_pixels(W, H, r, 3)
+        acc[xy[:, 1], xy[:, 0]] = part[xy[:, 1], xy[:, 0]]
+        owned[xy[:, 1], xy[:, 0]] += 1
+        other = np.ones((H, W), bool)
+        other[xy[:, 1], xy[:, 0]] = False
+        assert (part[other] == 0).all()  # a rank never touches pixels it does not own
+    assert (owned == 1).all()
+    assert np.array_equal(acc.view(np.uint32), full.view(np.uint32))
+
+
+def test_pack_unpack_tiles_roundtrip(small):
+    import torch
+
+    mesh, sky, bn, osc = small
+    W, H = 200, 150
+    pt = PathTracer((W, H))
+    pt.set_scene(mesh, sky, bn)
+    cam = Camera(scenes.ATRIUM_CAMERA["position"], scenes.ATRIUM_CAMERA["direction"], math.radians(65.0), W / H)
+    pt.render(pt.make_gconst(cam, 1, 2, flags=FULL))
+    ref = pt.light()
+    bufs = []
+    for r in range(4):
+        n = pt.ctx.tile_pixel_count(r, 4)
+        assert n == len(orc.tile_pixels(W, H, r, 4))
+        t = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+        pt.ctx.check(pt.ctx.lib.rt3_image_pack_tiles(pt.ctx.h, pt.handles["light"], r, 4, C.c_void_p(t.data_ptr())))
+        bufs.append(t)
+    pt.ctx.wait()
+    pt.rg.upload(pt.handles["light"], np.zeros_like(ref))
+    for r, t in enumerate(bufs):
+        pt.ctx.check(pt.ctx.lib.rt3_image_unpack_tiles(pt.ctx.h, pt.handles["light"], r, 4, C.c_void_p(t.data_ptr())))
+    assert np.array_equal(pt.light().view(np.uint32), ref.view(np.uint32))
+    pt.close()
+
+
+def test_sky_tables_match_oracle(small):
+    mesh, sky, bn, osc = small
+    ctx = Context(0)
+    ctx.set_sky(sky)
+    cc, cm, pu = ctx.sky_download(sky.shape[1], sky.shape[0])
+    occ, ocm, opu = osc.sky_tables(sky.shape[1], sky.shape[0])
+    assert np.array_equal(cc, occ) and np.array_equal(cm, ocm) and np.array_equal(pu, opu)
+    ctx.close()
+
+
+def test_error_behaviour(small):
+    """Every failure is a negative status + message, never an abort (SURVEY 8b 'Errors')."""
+    mesh, sky, bn, osc = small
+    ctx = Context(0)
+    lib = ctx.lib
+    g = L.GConst()
+    g.window_size[0], g.window_size[1] = 64, 64
+    b = (C.c_uint32 * 2)(0, 0)
+    # pass before accel build
+    assert lib.rt3_pass_launch(ctx.h, b"gbuffer", b"main", 64, 64, 1, C.byref(g), 304, b, 2) == L.E_STATE
+    ctx.upload_mesh(mesh)
+    ctx.build_accel()
+    assert lib.rt3_pass_launch(ctx.h, b"nope", b"main", 64, 64, 1, C.byref(g), 304, b, 2) == L.E_INVALID
+    assert b"unknown pass" in lib.rt3_last_error(ctx.h)
+    assert lib.rt3_pass_launch(ctx.h, b"gbuffer", b"other_entry", 64, 64, 1, C.byref(g), 304, b, 2) == L.E_INVALID
+    assert lib.rt3_pass_launch(ctx.h, b"gbuffer", b"main", 64, 64, 1, C.byref(g), 300, b, 2) == L.E_INVALID
+    assert lib.rt3_pass_launch(ctx.h, b"gbuffer", b"main", 64, 64, 1, C.byref(g), 304, b, 2) == L.E_INVALID  # handles are not images
+    img = C.c_uint32()
+    assert lib.rt3_image_create(ctx.h, 64, 64, 12345, C.byref(img)) == L.E_INVALID
+    assert lib.rt3_image_create(ctx.h, 64, 64, L.FORMAT_R32_SFLOAT, C.byref(img)) == 0
+    assert img.value >> 30 == L.TAG_IMAGE
+    # textures are not supported in this round
+    gi = mesh.geometries.copy()
+    gi["base_color_texture_index"][0] = 0
+    pc = np.ascontiguousarray(mesh.prim_counts)
+    assert lib.rt3_scene_set_geometry(ctx.h, gi.ctypes.data, pc.ctypes.data, len(gi)) == L.E_UNSUPPORTED
+    # out-of-range geometry is rejected on the host instead of faulting on the GPU
+    gi = mesh.geometries.copy()
+    gi["index_offset"][-1] = 2**31
+    assert lib.rt3_scene_set_geometry(ctx.h, gi.ctypes.data, pc.ctypes.data, len(gi)) == L.E_INVALID
+    ctx.close()
