@@ -59,6 +59,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own HIP runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).  Import it first so that the
+    # loader resolves librt3's NEEDED libamdhip64.so.7 to that already-loaded copy: two HIP runtimes in one process
+    # cannot both open the GPU ("No HIP GPUs are available").  Without torch, librt3 uses /opt/rocm's runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not LIB_PATH.exists():
         raise ImportError(f"{LIB_PATH} is missing: build it with `make -C {PKG / 'csrc'}` (hipcc, gfx950). There is no CPU fallback.")
     L = C.CDLL(str(LIB_PATH))

@@ -66,7 +66,7 @@ struct rt3_ctx {
     uint32_t bn_w = 0, bn_h = 0;
     LbvhResult bvh;
     bool accel_built = false;
-    uint32_t max_index_seen = 0;
+    std::vector<uint32_t> h_indices;  // host copy, only for range validation in rt3_scene_set_geometry
     // resources
     std::vector<Resource> resources;
     std::vector<PixelList> pixlists;
@@ -518,9 +518,7 @@ int rt3_scene_set_indices(rt3_ctx* c, const uint32_t* idx, uint32_t n) {
     if (int r = dev_alloc(c, &c->d_indices, (size_t)n)) return r;
     if (n) HIPC(c, hipMemcpy(c->d_indices, idx, (size_t)n * 4, hipMemcpyHostToDevice));
     c->n_indices = n;
-    uint32_t mx = 0;
-    for (uint32_t i = 0; i < n; i++) mx = idx[i] > mx ? idx[i] : mx;
-    c->max_index_seen = mx;
+    c->h_indices.assign(idx, idx + n);
     c->accel_built = false;
     return RT3_OK;
 }
@@ -533,7 +531,12 @@ int rt3_scene_set_geometry(rt3_ctx* c, const rt3_geometry_info* g, const uint32_
         if (g[i].base_color_texture_index > -1) return fail(c, RT3_E_UNSUPPORTED, "base-colour textures are not supported in this round (hit_logic.slang:31-33)");
         // bounds: the kernels index the world buffers without checks (a GPU fault would take the node down)
         if ((uint64_t)g[i].index_offset + 3ull * prim_counts[i] > c->n_indices) return fail(c, RT3_E_INVALID, "geometry index range exceeds the index buffer");
-        if ((uint64_t)g[i].vertex_offset + c->max_index_seen >= (uint64_t)c->n_verts && prim_counts[i])
+        uint32_t mx = 0;
+        for (uint64_t k = 0; k < 3ull * prim_counts[i]; k++) {
+            uint32_t v = c->h_indices[g[i].index_offset + k];
+            mx = v > mx ? v : mx;
+        }
+        if (prim_counts[i] && (uint64_t)g[i].vertex_offset + mx >= (uint64_t)c->n_verts)
             return fail(c, RT3_E_INVALID, "geometry vertex range exceeds the vertex buffer (set vertices and indices before geometry)");
         first[i] = (uint32_t)total;
         total += prim_counts[i];

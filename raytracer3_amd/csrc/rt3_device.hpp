@@ -33,7 +33,7 @@ RT3_DEV V3 neg(V3 a) { return V3{-a.x, -a.y, -a.z}; }
 RT3_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 RT3_DEV V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 RT3_DEV V3 normalize(V3 a) {
-    float inv = 1.0f / __fsqrt_rn(dot(a, a));
+    float inv = 1.0f / sqrtf(dot(a, a));
     return a * inv;
 }
 RT3_DEV float fmin_sel(float a, float b) { return a < b ? a : b; }
@@ -103,7 +103,7 @@ RT3_DEV V3 unpack_normal_11_10_11(uint32_t p) {  // :20-27
     return normalize(v3(unpack_unorm(p, 11) * 2.0f - 1.0f, unpack_unorm(p >> 11, 10) * 2.0f - 1.0f, unpack_unorm(p >> 21, 11) * 2.0f - 1.0f));
 }
 RT3_DEV uint32_t pack_color_888(V3 c) {  // :46-53
-    return pack_unorm(__fsqrt_rn(c.x), 8) + (pack_unorm(__fsqrt_rn(c.y), 8) << 8) + (pack_unorm(__fsqrt_rn(c.z), 8) << 16);
+    return pack_unorm(sqrtf(c.x), 8) + (pack_unorm(sqrtf(c.y), 8) << 8) + (pack_unorm(sqrtf(c.z), 8) << 16);
 }
 RT3_DEV V3 unpack_color_888(uint32_t p) {  // :55-62
     V3 c = v3(unpack_unorm(p, 8), unpack_unorm(p >> 8, 8), unpack_unorm(p >> 16, 8));
@@ -139,7 +139,7 @@ struct Surface {
     float roughness, metalness;
 };
 RT3_DEV uint4 gbuffer_pack(const Surface& s) {  // :22-34
-    return make_uint4(pack_color_888(s.albedo), pack_normal_11_10_11(s.normal), pack_2x16f(__fsqrt_rn(s.roughness), s.metalness),
+    return make_uint4(pack_color_888(s.albedo), pack_normal_11_10_11(s.normal), pack_2x16f(sqrtf(s.roughness), s.metalness),
                       float3_to_rgb9e5(s.emissive));
 }
 RT3_DEV Surface gbuffer_unpack(uint4 p) {  // :59-70
@@ -182,7 +182,7 @@ RT3_DEV float atan2_poly(float y, float x) {
 }
 // math.slang:6-12
 RT3_DEV void direction_to_equirect_uv(V3 d, float& u, float& v) {
-    float as = atan2_poly(d.y, __fsqrt_rn(fmax_sel(0.0f, 1.0f - d.y * d.y)));
+    float as = atan2_poly(d.y, sqrtf(fmax_sel(0.0f, 1.0f - d.y * d.y)));
     u = 0.5f + atan2_poly(d.z, d.x) / kTau;
     v = 0.5f - as / kPi;
 }
@@ -208,8 +208,8 @@ RT3_DEV V3 basis_apply(V3 b1, V3 b2, V3 n, V3 w) {
 RT3_DEV V3 diffuse_sample(float u0, float u1) {
     float sp, cp;
     sincos_2pi(u0, sp, cp);
-    float cos_theta = __fsqrt_rn(fmax_sel(0.0f, 1.0f - u1));
-    float sin_theta = __fsqrt_rn(fmax_sel(0.0f, 1.0f - cos_theta * cos_theta));
+    float cos_theta = sqrtf(fmax_sel(0.0f, 1.0f - u1));
+    float sin_theta = sqrtf(fmax_sel(0.0f, 1.0f - cos_theta * cos_theta));
     return v3(cp * sin_theta, sp * sin_theta, cos_theta);
 }
 

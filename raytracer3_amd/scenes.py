@@ -16,7 +16,9 @@ from .assets import Material, Mesh, MeshBuilder
 ATRIUM_SEED = 0x5F0A2A
 SKY_SEED = 7
 ATRIUM_CAMERA = dict(position=(-10.0, 2.0, 0.0), direction=(1.0, 0.1, 0.0), fov_deg=65.0)
-CORNELL_CAMERA = dict(position=(0.0, 1.0, 3.4), direction=(0.0, 0.0, -1.0), fov_deg=40.0)
+# slightly off-axis: an exactly symmetric view sends rays through the shared diagonals of the wall quads, where the fp32
+# Moeller-Trumbore test is not watertight (known limitations)
+CORNELL_CAMERA = dict(position=(0.0137, 1.0071, 3.4), direction=(0.0041, -0.0033, -1.0), fov_deg=40.0)
 
 
 def _grid(origin, du, dv, nu, nv, normal=None, disp=None):

@@ -190,7 +190,10 @@ def test_frame_parity_cornell_reference_semantics(cornell):
     olight, counts = osc.reference_mode(og, ogb, odepth)
     assert np.array_equal(light.view(np.uint32), olight.view(np.uint32))
     assert light[..., :3].mean() > 0.01
-    assert st.extension_rays == W * H + W * H * 16 * 3  # nothing escapes a closed box
+    assert st.extension_rays == W * H + int(counts[0])
+    # (almost) nothing escapes a closed box: hit points are not offset along the normal (refrence_mode.slang:47) and fp32
+    # Moeller-Trumbore is not watertight, so a few grazing rays near corners leave
+    assert int(counts[0]) >= 0.999 * W * H * 16 * 3
 
 
 def test_batching_and_blend_do_not_change_the_image(small):
