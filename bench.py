@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--detail", type=float, default=1.0)
     ap.add_argument("--batch-spp", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-crop", type=str, default="320x180")
+    ap.add_argument("--cpu-crop", type=str, default="960x540")
     args = ap.parse_args()
 
     import numpy as np
@@ -154,7 +154,7 @@ def main():
         cw, ch = min(cw, W), min(ch, H)
         x0, y0 = (W - cw) // 2, (H - ch) // 2
         rect = (x0, y0, x0 + cw, y0 + ch)
-        threads = os.cpu_count() or 1
+        threads = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 256)
         osc = orc.Scene(mesh, sky, bn)
         og = orc.GConst()
         C.memmove(C.byref(og), C.byref(g_last), 304)

@@ -23,7 +23,7 @@ EXPORTS = [
     "rt3_accel_build", "rt3_accel_info", "rt3_accel_download", "rt3_sky_download",
     "rt3_buffer_create", "rt3_image_create", "rt3_image_import", "rt3_resource_upload", "rt3_resource_download", "rt3_resource_device_ptr",
     "rt3_set_tile_partition", "rt3_tile_pixel_count", "rt3_image_pack_tiles", "rt3_image_unpack_tiles",
-    "rt3_pass_launch", "rt3_frame_wait", "rt3_trace_rays", "rt3_stats_reset", "rt3_stats_get", "rt3_camera_gconst",
+    "rt3_pass_launch", "rt3_frame_wait", "rt3_trace_rays", "rt3_selftest_eval", "rt3_stats_reset", "rt3_stats_get", "rt3_camera_gconst",
 ]
 
 
@@ -99,6 +99,7 @@ def load():
         "rt3_pass_launch": (i32, [vp, C.c_char_p, C.c_char_p, u32, u32, u32, vp, sz, pu32, u32]),
         "rt3_frame_wait": (i32, [vp]),
         "rt3_trace_rays": (i32, [vp, vp, u32, i32, vp, vp, vp, vp, vp, vp, i32, C.POINTER(C.c_double)]),
+        "rt3_selftest_eval": (i32, [vp, i32, vp, u32, vp]),
         "rt3_stats_reset": (i32, [vp]),
         "rt3_stats_get": (i32, [vp, C.POINTER(Stats)]),
         "rt3_camera_gconst": (None, [C.POINTER(f32), C.POINTER(f32), f32, f32, f32, f32, f32, f32, C.POINTER(GConst)]),

@@ -77,11 +77,13 @@ class MeshBuilder:
         self.nv = 0
         self.ni = 0
 
-    def add(self, name, pos, nrm, uv, tris, mat: Material):
+    def add(self, name, pos, nrm, uv, tris, mat: Material, normalize=True):
         pos = np.asarray(pos, np.float32).reshape(-1, 3)
+        if normalize:
+            nrm = np.asarray(nrm, np.float64).reshape(-1, 3)
+            ln = np.linalg.norm(nrm, axis=1, keepdims=True)
+            nrm = nrm / np.maximum(ln, 1e-20)
         nrm = np.asarray(nrm, np.float32).reshape(-1, 3)
-        ln = np.linalg.norm(nrm, axis=1, keepdims=True)
-        nrm = (nrm / np.maximum(ln, 1e-20)).astype(np.float32)
         uv = np.zeros((len(pos), 2), np.float32) if uv is None else np.asarray(uv, np.float32).reshape(-1, 2)
         tris = np.asarray(tris, np.uint32).reshape(-1, 3)
         assert tris.size == 0 or int(tris.max()) < len(pos)
@@ -136,7 +138,8 @@ def write_glb(path, mesh: Mesh) -> None:
     for gi, (g, cnt) in enumerate(zip(mesh.geometries, mesh.prim_counts)):
         io, vo, cnt = int(g["index_offset"]), int(g["vertex_offset"]), int(cnt)
         idx = mesh.indices[io : io + 3 * cnt]
-        nv = int(idx.max()) + 1 if cnt else 0
+        later = [int(x) for x in mesh.geometries["vertex_offset"] if int(x) > vo]
+        nv = (min(later) if later else len(mesh.vertices)) - vo  # keep unreferenced vertices: the round trip is exact
         v = mesh.vertices[vo : vo + nv]
         acc = []
         for col, typ in ((slice(0, 3), "VEC3"), (slice(3, 6), "VEC3"), (slice(6, 8), "VEC2")):
@@ -254,10 +257,15 @@ class GltfMeshLoader:
                     if prim.get("mode", 4) != 4:
                         continue
                     at = prim["attributes"]
+                    identity = np.array_equal(m, np.eye(4))
                     pos = accessor(at["POSITION"]).astype(np.float64)
-                    pos = (pos @ m[:3, :3].T + m[:3, 3]).astype(np.float32)
+                    pos = (pos if identity else pos @ m[:3, :3].T + m[:3, 3]).astype(np.float32)
+                    keep = False
                     if "NORMAL" in at:
-                        nrm = accessor(at["NORMAL"]).astype(np.float64) @ nm.T
+                        nrm = accessor(at["NORMAL"])
+                        keep = identity and nrm.dtype == np.float32  # stored unit normals pass through bit for bit
+                        if not keep:
+                            nrm = nrm.astype(np.float64) @ nm.T
                     else:
                         nrm = None
                     uv = accessor(at["TEXCOORD_0"]).astype(np.float32) if "TEXCOORD_0" in at else None
@@ -277,7 +285,7 @@ class GltfMeshLoader:
                         em = em * gmtl.get("extensions", {}).get("KHR_materials_emissive_strength", {}).get("emissiveStrength", 1.0)
                         tex = pbr.get("baseColorTexture", {}).get("index", -1)
                         mat = Material(tuple(bc[:3]), pbr.get("metallicFactor", 1.0), pbr.get("roughnessFactor", 1.0), tuple(em), tex)
-                    mb.add(f"{gm.get('name', 'mesh')}.{pi}", pos, nrm, uv, tris, mat)
+                    mb.add(f"{gm.get('name', 'mesh')}.{pi}", pos, nrm, uv, tris, mat, normalize=not keep)
             for c in node.get("children", []):
                 visit(c, m)
 

@@ -864,6 +864,29 @@ int rt3_trace_rays(rt3_ctx* c, const float* rays, uint32_t n, int any_hit, float
     return RT3_OK;
 }
 
+int rt3_selftest_eval(rt3_ctx* c, int op, const void* in, uint32_t n, void* out) {
+    uint32_t iw, ow;
+    if (!c || !in || !out || !selftest_widths(op, &iw, &ow)) return fail(c, RT3_E_INVALID, "selftest: bad op / NULL");
+    if (n == 0) return RT3_OK;
+    HIPC(c, hipSetDevice(c->device));
+    uint32_t *d_in = nullptr, *d_out = nullptr;
+    HIPC(c, hipMalloc((void**)&d_in, (size_t)n * iw * 4));
+    if (hipMalloc((void**)&d_out, (size_t)n * ow * 4) != hipSuccess) {
+        (void)hipFree(d_in);
+        return fail(c, RT3_E_HIP, "selftest: hipMalloc failed");
+    }
+    hipError_t e = hipMemcpy(d_in, in, (size_t)n * iw * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch_selftest(c->stream, op, d_in, n, d_out);
+        e = hipStreamSynchronize(c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d_out, (size_t)n * ow * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
+    if (e != hipSuccess) return fail(c, RT3_E_HIP, std::string("selftest: ") + hipGetErrorString(e));
+    return RT3_OK;
+}
+
 int rt3_stats_reset(rt3_ctx* c) {
     if (!c) return RT3_E_INVALID;
     HIPC(c, hipSetDevice(c->device));

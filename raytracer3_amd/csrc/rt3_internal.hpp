@@ -61,6 +61,9 @@ void launch_postprocess(hipStream_t st, const GConstDev& g, const SceneDev& sc, 
 void launch_pack_tiles(hipStream_t st, const uint32_t* pixels, uint32_t npix, uint32_t width, const void* img, void* dst);
 void launch_unpack_tiles(hipStream_t st, const uint32_t* pixels, uint32_t npix, uint32_t width, const void* src, void* img);
 
+bool selftest_widths(int op, uint32_t* in_w, uint32_t* out_w);
+void launch_selftest(hipStream_t st, int op, const uint32_t* in, uint32_t n, uint32_t* out);
+
 // LBVH build (rt3_lbvh.hip).  All pointers are device memory owned by the caller except the scratch the builder
 // allocates and frees itself.  Returns hipSuccess or the failing HIP error; *max_depth is read back to the host.
 struct LbvhResult {

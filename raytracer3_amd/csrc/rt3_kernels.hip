@@ -473,6 +473,79 @@ __global__ void k_unpack_tiles(const uint32_t* __restrict__ pixels, uint32_t npi
     }
 }
 
+// ------------------------------------------------------------------------------------------------ self-test
+// Evaluates one device function per element so that tests can pin the device arithmetic against known answers
+// (rt3_selftest_eval).  in / out are dense arrays of `in_w` / `out_w` 32-bit words per element.
+__global__ void k_selftest(int op, const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    auto F = [](uint32_t u) { return __uint_as_float(u); };
+    auto U = [](float f) { return __float_as_uint(f); };
+    switch (op) {
+        case 0: out[i] = jenkins_hash(in[i]); break;
+        case 1: out[i] = zcurve(in[2 * i], in[2 * i + 1]); break;
+        case 2: out[i] = murmur3(in[2 * i], in[2 * i + 1]); break;
+        case 3: out[i] = U(uniform_float(in[2 * i], in[2 * i + 1])); break;
+        case 4: {
+            const uint32_t* p = in + 11 * i;
+            Surface s;
+            s.albedo = v3(F(p[0]), F(p[1]), F(p[2]));
+            s.emissive = v3(F(p[3]), F(p[4]), F(p[5]));
+            s.normal = v3(F(p[6]), F(p[7]), F(p[8]));
+            s.roughness = F(p[9]);
+            s.metalness = F(p[10]);
+            uint4 q = gbuffer_pack(s);
+            out[4 * i] = q.x; out[4 * i + 1] = q.y; out[4 * i + 2] = q.z; out[4 * i + 3] = q.w;
+            break;
+        }
+        case 5: {
+            Surface s = gbuffer_unpack(make_uint4(in[4 * i], in[4 * i + 1], in[4 * i + 2], in[4 * i + 3]));
+            uint32_t* o = out + 11 * i;
+            o[0] = U(s.albedo.x); o[1] = U(s.albedo.y); o[2] = U(s.albedo.z);
+            o[3] = U(s.emissive.x); o[4] = U(s.emissive.y); o[5] = U(s.emissive.z);
+            o[6] = U(s.normal.x); o[7] = U(s.normal.y); o[8] = U(s.normal.z);
+            o[9] = U(s.roughness); o[10] = U(s.metalness);
+            break;
+        }
+        case 6: {
+            V3 w = diffuse_sample(F(in[2 * i]), F(in[2 * i + 1]));
+            out[3 * i] = U(w.x); out[3 * i + 1] = U(w.y); out[3 * i + 2] = U(w.z);
+            break;
+        }
+        case 7: {
+            V3 b1, b2;
+            build_orthonormal_basis(v3(F(in[3 * i]), F(in[3 * i + 1]), F(in[3 * i + 2])), b1, b2);
+            uint32_t* o = out + 6 * i;
+            o[0] = U(b1.x); o[1] = U(b1.y); o[2] = U(b1.z); o[3] = U(b2.x); o[4] = U(b2.y); o[5] = U(b2.z);
+            break;
+        }
+        case 8: {
+            V3 r = agx_tonemap(v3(F(in[3 * i]), F(in[3 * i + 1]), F(in[3 * i + 2])));
+            out[3 * i] = U(r.x); out[3 * i + 1] = U(r.y); out[3 * i + 2] = U(r.z);
+            break;
+        }
+        case 9: {
+            float sn, cs;
+            sincos_2pi(F(in[i]), sn, cs);
+            out[2 * i] = U(sn); out[2 * i + 1] = U(cs);
+            break;
+        }
+        case 10: out[i] = U(atan2_poly(F(in[2 * i]), F(in[2 * i + 1]))); break;
+        case 11: out[i] = rng_seed(in[3 * i], in[3 * i + 1], in[3 * i + 2]); break;
+        default: break;
+    }
+}
+bool selftest_widths(int op, uint32_t* in_w, uint32_t* out_w) {
+    static const uint32_t w[12][2] = {{1, 1}, {2, 1}, {2, 1}, {2, 1}, {11, 4}, {4, 11}, {2, 3}, {3, 6}, {3, 3}, {1, 2}, {2, 1}, {3, 1}};
+    if (op < 0 || op > 11) return false;
+    *in_w = w[op][0];
+    *out_w = w[op][1];
+    return true;
+}
+void launch_selftest(hipStream_t st, int op, const uint32_t* in, uint32_t n, uint32_t* out) {
+    hipLaunchKernelGGL(k_selftest, dim3((n + 255) / 256), dim3(256), 0, st, op, in, n, out);
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 static inline unsigned grid_for(uint64_t n, unsigned block, unsigned max_blocks) {
     uint64_t b = (n + block - 1) / block;

@@ -214,6 +214,15 @@ class Context:
                                            cn.ctypes.data if counts else None, ct.ctypes.data if counts else None, repeat, C.byref(ms)))
         return (t, u, v, prim, cn, ct, ms.value) if counts else (t, u, v, prim, ms.value)
 
+    def selftest(self, op, inp, out_words, out_dtype=np.uint32):
+        """Evaluate device function `op` (include/rt3.h: rt3_selftest_eval) on the rows of `inp` (32-bit words)."""
+        inp = np.ascontiguousarray(inp)
+        assert inp.dtype.itemsize == 4
+        n = inp.shape[0]
+        out = np.zeros((n, out_words), out_dtype)
+        self.check(self.lib.rt3_selftest_eval(self.h, op, inp.ctypes.data, n, out.ctypes.data))
+        return out
+
     def stats_reset(self):
         self.check(self.lib.rt3_stats_reset(self.h))
 

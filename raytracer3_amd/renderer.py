@@ -119,25 +119,43 @@ class PathTracer:
     def gather_light(self, dist=None, torch=None, dst=0):
         """Pack this rank's tiles of `Light`, gather them on `dst` with ONE collective and untile there.
         Returns the full (H, W, 4) image on `dst` (None elsewhere).  With n_ranks == 1 no collective is issued."""
-        W, H = self.window
         if self.n_ranks == 1:
             return self.light()
         counts = [self.tile_pixel_count(r) for r in range(self.n_ranks)]
-        cap = max(counts)
         dev = torch.device("cuda", torch.cuda.current_device())
-        mine = torch.zeros((cap, 4), dtype=torch.float32, device=dev)
-        self.ctx.check(self.ctx.lib.rt3_image_pack_tiles(self.ctx.h, self.handles["light"], self.rank, self.n_ranks, C.c_void_p(mine.data_ptr())))
-        self.ctx.wait()
-        if self.rank == dst:
-            parts = [torch.empty_like(mine) for _ in range(self.n_ranks)]
-            dist.gather(mine, parts, dst=dst)
+        lib, h, img = self.ctx.lib, self.ctx.h, self.handles["light"]
+
+        def pack(buf):
+            self.ctx.check(lib.rt3_image_pack_tiles(h, img, self.rank, self.n_ranks, C.c_void_p(buf.data_ptr())))
+            self.ctx.wait()  # librt3 runs on its own stream: the tile buffer must be complete before RCCL reads it
+
+        def unpack(r, buf):
             torch.cuda.synchronize()
-            for r, p in enumerate(parts):
-                self.ctx.check(self.ctx.lib.rt3_image_unpack_tiles(self.ctx.h, self.handles["light"], r, self.n_ranks, C.c_void_p(p.data_ptr())))
-            self.ctx.wait()
-            return self.light()
-        dist.gather(mine, None, dst=dst)
-        return None
+            self.ctx.check(lib.rt3_image_unpack_tiles(h, img, r, self.n_ranks, C.c_void_p(buf.data_ptr())))
+
+        done = gather_tiles(dist, torch, dev, self.rank, self.n_ranks, counts, pack, unpack, dst)
+        if not done:
+            return None
+        self.ctx.wait()
+        return self.light()
+
+
+def gather_tiles(dist, torch, device, rank, n_ranks, counts, pack, unpack, dst=0):
+    """The one collective of a frame (north_star): every rank contributes its contiguous tile buffer
+    (max(counts) x RGBA32F, zero padded) to ONE `dist.gather` on `dst`; `dst` hands each received buffer to `unpack`.
+    `pack(buf)` fills this rank's buffer, `unpack(r, buf)` scatters rank r's pixels into the full image.
+    Backend-agnostic (nccl == RCCL on the GPUs, gloo in the CPU tests).  Returns True on `dst`."""
+    cap = max(counts)
+    mine = torch.zeros((cap, 4), dtype=torch.float32, device=device)
+    pack(mine)
+    if rank == dst:
+        parts = [torch.empty_like(mine) for _ in range(n_ranks)]
+        dist.gather(mine, parts, dst=dst)
+        for r, p in enumerate(parts):
+            unpack(r, p)
+        return True
+    dist.gather(mine, None, dst=dst)
+    return False
 
 
 def default_camera(window, position, direction, fov_deg):

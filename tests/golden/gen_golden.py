@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures from the CPU oracle (the reference ships no golden vectors).
+Run from the repo root:  python tests/golden/gen_golden.py
+A fixture = inputs (scene arrays, GConst bytes, rays) + the oracle's outputs; tests check that both the oracle (CPU
+suite) and the HIP path (GPU suite) still reproduce them bit for bit."""
+import ctypes as C
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import orc  # noqa: E402
+from raytracer3_amd import assets, scenes  # noqa: E402
+
+OUT = Path(__file__).resolve().parent
+
+
+def gbytes(g):
+    return np.frombuffer(bytes(g), np.uint8).copy()
+
+
+def scene_fixture(name, mesh, sky, bn, cam, W, H, spp, bounces, flags, frame):
+    osc = orc.Scene(mesh, sky, bn)
+    g = orc.camera_gconst(width=W, height=H, **cam)
+    g.bounces, g.samples, g.blendfactor, g.frame = bounces, spp, 1.0, frame
+    g.pad[0] = flags
+    gb, depth = osc.gbuffer(g)
+    light, counts = osc.reference_mode(g, gb, depth)
+    rng = np.random.default_rng(42)
+    ys, xs = rng.integers(0, H, 2048), rng.integers(0, W, 2048)
+    prim = orc.primary_rays(g, xs, ys)
+    lo, hi = mesh.vertices[:, :3].min(0) + 0.05, mesh.vertices[:, :3].max(0) - 0.05
+    o = rng.uniform(lo, hi, (2048, 3)).T
+    d = rng.normal(size=(3, 2048)); d /= np.linalg.norm(d, axis=0)
+    rnd = np.concatenate([o, d, np.full((1, 2048), 0.001), np.full((1, 2048), 1e5)]).astype(np.float32)
+    rays = np.concatenate([prim, rnd], axis=1)
+    t, u, v, p, nn, nt = osc.trace_closest(rays, counts=True)
+    bt, bu, bv, bp = osc.trace_brute(rays, 0)
+    assert np.array_equal(p, bp) and np.array_equal(t, bt), "BVH traversal disagrees with the brute-force fp32 intersector"
+    occ = osc.trace_any(rays)
+    np.savez_compressed(OUT / f"{name}.npz", vertices=mesh.vertices, indices=mesh.indices, geometries=mesh.geometries, prim_counts=mesh.prim_counts,
+                        sky=(sky if sky is not None else np.zeros((0, 0, 3), np.float32)), gconst=gbytes(g), gbuffer=gb, depth=depth, light=light,
+                        counts=counts, rays=rays, hit_t=t, hit_u=u, hit_v=v, hit_prim=p, n_nodes=nn, n_tris=nt, occluded=occ,
+                        bvh_nodes=osc.nodes()[:, :14], bvh_tris=osc.tris())
+    print(name, mesh.n_triangles, "tris", W, H, "mean", float(light[..., :3].mean()), "file KB", (OUT / f"{name}.npz").stat().st_size // 1024)
+
+
+def function_fixture():
+    L = orc.lib()
+    rng = np.random.default_rng(7)
+    surf = np.zeros((64, 11), np.float32)
+    surf[:, 0:3] = rng.uniform(0, 1, (64, 3))
+    surf[:, 3:6] = rng.uniform(0, 1, (64, 3)) * 10 ** rng.uniform(-3, 2, (64, 1))
+    n = rng.normal(size=(64, 3)); surf[:, 6:9] = n / np.linalg.norm(n, axis=1, keepdims=True)
+    surf[:, 9] = rng.uniform(0, 1, 64); surf[:, 10] = rng.uniform(0, 1, 64)
+    packed = np.zeros((64, 4), np.uint32); unpacked = np.zeros((64, 11), np.float32)
+    for i in range(64):
+        L.orc_gbuffer_pack(orc.ptr(surf[i]), orc.ptr(packed[i]))
+        L.orc_gbuffer_unpack(orc.ptr(packed[i]), orc.ptr(unpacked[i]))
+    us = (np.arange(8) + 0.5) / 8
+    grid = np.array([(a, b) for a in us for b in us], np.float32)
+    wi = np.zeros((64, 3), np.float32)
+    for i, (a, b) in enumerate(grid):
+        L.orc_diffuse_sample(float(a), float(b), orc.ptr(wi[i]))
+    normals = np.concatenate([np.eye(3), -np.eye(3), surf[:16, 6:9]]).astype(np.float32)
+    onb = np.zeros((len(normals), 6), np.float32)
+    for i, nn in enumerate(normals):
+        L.orc_onb(orc.ptr(np.ascontiguousarray(nn)), orc.ptr(onb[i, :3]), orc.ptr(onb[i, 3:]))
+    x = np.logspace(-4, 2, 32).astype(np.float32)
+    agx = np.zeros((32, 3), np.float32)
+    for i, v in enumerate(x):
+        L.orc_agx_tonemap(orc.ptr(np.array([v, v * 0.5, v * 0.25], np.float32)), orc.ptr(agx[i]))
+    seeds = np.array([[0, 0, 0], [1, 0, 0], [960, 540, 7], [1919, 1079, 63]], np.uint32)
+    rnd = np.array([[L.orc_murmur3(L.orc_rng_seed(int(a), int(b), int(c)), k) for k in range(8)] for a, b, c in seeds], np.uint32)
+    np.savez_compressed(OUT / "functions.npz", surf=surf, packed=packed, unpacked=unpacked, urand=grid, diffuse_wi=wi, normals=normals, onb=onb,
+                        agx_in=x, agx_out=agx, rng_seeds=seeds, rng_out=rnd)
+    print("functions", (OUT / "functions.npz").stat().st_size // 1024, "KB")
+
+
+if __name__ == "__main__":
+    bn = assets.load_bluenoise()
+    FULL = orc.F_NEE_SKY | orc.F_BLUENOISE | orc.F_FACEFORWARD
+    scene_fixture("cornell_ref", scenes.cornell(), None, None, scenes.CORNELL_CAMERA, 64, 64, 4, 4, 0, 2)
+    scene_fixture("atrium_full", scenes.atrium(0.2), scenes.sky(64, 32), bn, scenes.ATRIUM_CAMERA, 64, 36, 4, 4, FULL, 5)
+    function_fixture()

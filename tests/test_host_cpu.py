@@ -1,0 +1,175 @@
+"""CPU-side checks of the product's host layer: the C-ABI library loads and exports every symbol of include/rt3.h,
+refuses to run without a GPU, and the Python mirror of the reference pass graph orders / binds passes like bake.rs."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import orc
+from raytracer3_amd import _lib as L
+from raytracer3_amd import assets, scenes
+from raytracer3_amd.render_graph import IMPORTED, ComputePass, DispatchSize, ImageSize, NodeBuilder, RayTracingPass, RenderGraph, WorkSize2D
+from raytracer3_amd.renderer import Camera
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load()
+    header = (ROOT / "include" / "rt3.h").read_text()
+    declared = set(re.findall(r"\b(rt3_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_no_cpu_fallback(has_gpu):
+    if has_gpu:
+        pytest.skip("GPU present")
+    lib = L.load()
+    h = C.c_void_p()
+    assert lib.rt3_create(0, C.byref(h)) == L.E_NO_DEVICE
+    assert b"no CPU fallback" in lib.rt3_last_error(None)
+
+
+def test_gconst_layout_matches_reference_offsets():
+    # renderer/mod.rs:47-63 -> offsets 0,64,128,192,256,264,268,272,276,280,284,288,296
+    exp = dict(proj=0, view=64, proj_inverse=128, view_inverse=192, window_size=256, frame=264, blendfactor=268, bounces=272, samples=276,
+               proberng=280, cell_size=284, mouse=288, pad=296)
+    for k, v in exp.items():
+        assert getattr(L.GConst, k).offset == v
+        assert getattr(orc.GConst, k).offset == v
+    assert C.sizeof(L.GConst) == 304
+    assert assets.GEOMETRY_DTYPE.itemsize == 64 and assets.GEOMETRY_DTYPE.fields["emission"][1] == 32 and assets.GEOMETRY_DTYPE.fields["roughness"][1] == 48
+
+
+def test_camera_matches_oracle_and_reference_defaults():
+    cam = Camera((0, 0, -1), (0, 0, 1), np.deg2rad(65.0), 1920 / 1088)  # main.rs:69-76
+    g = cam.gconst((1920, 1088))
+    o = orc.camera_gconst((0, 0, -1), (0, 0, 1), 65.0, 1920, 1088)
+    for f in ("proj", "view", "proj_inverse", "view_inverse"):
+        assert np.allclose(np.array(getattr(g, f)[:]), np.array(getattr(o, f)[:]), rtol=2e-6, atol=1e-7), f
+    assert tuple(g.window_size) == (1920.0, 1088.0) and g.blendfactor == 1.0
+
+
+class FakeCtx:
+    """Records rt3_pass_launch calls instead of running them (no GPU in the build container)."""
+
+    def __init__(self):
+        self.calls, self.n = [], 0
+        self.lib, self.h = self, None
+
+    def check(self, rc):
+        assert rc == 0
+
+    def rt3_image_create(self, h, w, hh, fmt, out):
+        self.n += 1
+        out._obj.value = (1 << 30) | self.n
+        return 0
+
+    def rt3_pass_launch(self, h, path, entry, x, y, z, cst, size, b, nb):
+        self.calls.append((path.decode(), entry.decode(), x, y, z, size, [b[i] for i in range(nb)]))
+        return 0
+
+    def wait(self):
+        pass
+
+
+def build_frame(rg, g):
+    gbuffer = rg.image(ImageSize.FullScreen, L.FORMAT_R32G32B32A32_UINT, "gbuffer")
+    depth = rg.image(ImageSize.FullScreen, L.FORMAT_R32_SFLOAT, "gbuffer_depth")
+    light = rg.image(ImageSize.FullScreen, L.FORMAT_R32G32B32A32_SFLOAT, "Light")
+    prev = rg.image(ImageSize.FullScreen, L.FORMAT_R32G32B32A32_SFLOAT, "PrevLight")
+    out = rg.image(ImageSize.FullScreen, L.FORMAT_R32G32B32A32_SFLOAT, "color")
+    # declared out of execution order on purpose: bake() must order by data dependencies (bake.rs:29-49)
+    gb = RayTracingPass.new(rg, "gbuffer").shader("gbuffer").constants(g).write(IMPORTED, gbuffer).write(IMPORTED, depth).launch(WorkSize2D.FullScreen)
+    unrelated = ComputePass.new(rg, "unused").shader("postprocess").constants(g).write(IMPORTED, prev).dispatch(DispatchSize.XY(1, 1))
+    pt = (RayTracingPass.new(rg, "refrence_mode").shader("refrence_mode").constants(g).read(gb, gbuffer).read(gb, depth)
+          .write(IMPORTED, light).read(IMPORTED, prev).launch(WorkSize2D.FullScreen))
+    ComputePass.new(rg, "postprocess").shader("postprocess").constants(g).read(gb, depth).write(IMPORTED, out).read(pt, light).dispatch(DispatchSize.FullScreen)
+    return dict(gbuffer=gbuffer, depth=depth, light=light, prev=prev, out=out, unrelated=unrelated)
+
+
+def test_render_graph_orders_and_binds_like_the_reference():
+    ctx = FakeCtx()
+    rg = RenderGraph(ctx, (1920, 1080))
+    g = L.GConst()
+    h = build_frame(rg, g)
+    rg.draw_frame(h["out"])
+    names = [c[0] for c in ctx.calls]
+    assert names == ["gbuffer", "refrence_mode", "postprocess"]  # the node that does not feed the output is culled
+    gbc, ptc, ppc = ctx.calls
+    assert gbc[2:5] == (1920, 1080, 1) and ptc[2:5] == (1920, 1080, 1)  # WorkSize2D::FullScreen = window exactly
+    assert ppc[2:5] == (240, 135, 1)  # DispatchSize::FullScreen = ceil(W/8) x ceil(H/8) groups (build.rs:254-258)
+    assert gbc[6] == [h["gbuffer"], h["depth"]]
+    assert ptc[6] == [h["gbuffer"], h["depth"], h["light"], h["prev"]]  # builder call order (bake.rs:51-83)
+    assert ppc[6] == [h["depth"], h["out"], h["light"]]
+    assert all(c[5] == 304 and c[1] == "main" for c in ctx.calls)
+    # named resources are created once and looked up afterwards (mod.rs:440-483)
+    assert rg.image(ImageSize.FullScreen, L.FORMAT_R32_SFLOAT, "gbuffer_depth") == h["depth"]
+    assert rg.frame_number == 1
+
+
+def test_render_graph_builder_errors():
+    ctx = FakeCtx()
+    rg = RenderGraph(ctx, (64, 64))
+    g = L.GConst()
+    a = rg.image(ImageSize.FullScreen, L.FORMAT_R32_SFLOAT, "a")
+    n0 = RayTracingPass.new(rg, "p0").shader("gbuffer").constants(g).read(IMPORTED, a).launch()
+    with pytest.raises(ValueError, match="allready used"):  # build.rs:57-59
+        RayTracingPass.new(rg, "p0")
+    with pytest.raises(ValueError, match="does not write"):  # build.rs:104-106
+        RayTracingPass.new(rg, "p1").read(n0, a)
+    b = rg.image(ImageSize.XY(8, 8), L.FORMAT_R32_SFLOAT, "b")
+    with pytest.raises(ValueError, match="doesnt write"):  # build.rs:97-103
+        RayTracingPass.new(rg, "p2").read(n0, b)
+    with pytest.raises(ValueError, match="duplicate"):  # build.rs:195-198
+        RayTracingPass.new(rg, "p3").write(IMPORTED, a).read_write(IMPORTED, a).launch()
+    assert ImageSize.FractionalFullScreen(8, 8).size((1920, 1080)) == (240, 135)  # build.rs:219-226 ceil-div
+    assert WorkSize2D.X(7).size((1, 1)) == (7, 1)
+
+
+def test_glb_and_exr_roundtrip(tmp_path):
+    mesh = scenes.atrium(0.1)
+    p = tmp_path / "a.glb"
+    assets.write_glb(p, mesh)
+    back = assets.GltfMeshLoader.load(p)
+    assert np.array_equal(back.vertices, mesh.vertices) and np.array_equal(back.indices, mesh.indices)
+    assert np.array_equal(back.prim_counts, mesh.prim_counts)
+    for f in ("base_color", "metallic_factor", "roughness", "emission", "index_offset", "vertex_offset"):
+        assert np.array_equal(back.geometries[f], mesh.geometries[f]), f
+    sky = scenes.sky(64, 32)
+    e = tmp_path / "s.exr"
+    assets.write_exr(e, sky)
+    assert np.array_equal(assets.read_exr(e), sky)
+    bn = assets.load_bluenoise()
+    assert bn.shape == (256, 256, 4) and abs(bn.mean() - 127.5) < 0.01  # 4 independent uniform channels
+
+
+def test_glb_node_transforms_are_baked(tmp_path):
+    import json, struct
+
+    tri = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], "<f4")
+    idx = np.array([0, 1, 2], "<u2")
+    blob = tri.tobytes() + idx.tobytes() + b"\0\0"
+    doc = {"asset": {"version": "2.0"}, "scene": 0, "scenes": [{"nodes": [0]}],
+           "nodes": [{"children": [1], "translation": [10, 0, 0]}, {"mesh": 0, "scale": [2, 2, 2]}],
+           "meshes": [{"primitives": [{"attributes": {"POSITION": 0}, "indices": 1}, {"attributes": {"POSITION": 0}, "indices": 1, "material": 0}]}],
+           "materials": [{"pbrMetallicRoughness": {"baseColorFactor": [0.1, 0.2, 0.3, 1], "roughnessFactor": 0.5, "metallicFactor": 0.25},
+                          "emissiveFactor": [1, 1, 1], "extensions": {"KHR_materials_emissive_strength": {"emissiveStrength": 3.0}}}],
+           "accessors": [{"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}, {"bufferView": 1, "componentType": 5123, "count": 3, "type": "SCALAR"}],
+           "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 36}, {"buffer": 0, "byteOffset": 36, "byteLength": 6}],
+           "buffers": [{"byteLength": len(blob)}]}
+    js = json.dumps(doc).encode()
+    js += b" " * ((-len(js)) % 4)
+    p = tmp_path / "t.glb"
+    p.write_bytes(struct.pack("<4sII", b"glTF", 2, 12 + 8 + len(js) + 8 + len(blob)) + struct.pack("<I4s", len(js), b"JSON") + js
+                  + struct.pack("<I4s", len(blob), b"BIN\0") + blob)
+    m = assets.GltfMeshLoader.load(p)
+    assert m.n_triangles == 2 and len(m.geometries) == 2  # both primitives (the reference reads only the first, assets/mod.rs:221)
+    assert np.allclose(m.vertices[:3, :3], tri * 2 + [10, 0, 0])
+    assert np.allclose(m.vertices[:3, 3:6], [0, 0, 1])  # flat normal generated, transformed by the inverse transpose
+    assert np.allclose(m.geometries["base_color"][1], [0.1, 0.2, 0.3, 1]) and np.isclose(m.geometries["roughness"][1], 0.5)
+    assert np.allclose(m.geometries["emission"][1][:3], 3.0) and np.isclose(m.geometries["metallic_factor"][1], 0.25)

@@ -1,0 +1,58 @@
+"""The oracle's LBVH + fp32 Moeller-Trumbore pinned against brute force (fp32: exact; fp64: up to grazing cases)."""
+import numpy as np
+
+import orc
+from raytracer3_amd import scenes
+
+
+def random_rays(n, seed, lo, hi):
+    rng = np.random.default_rng(seed)
+    o = rng.uniform(lo, hi, (n, 3)).T
+    d = rng.normal(size=(3, n))
+    d /= np.linalg.norm(d, axis=0)
+    return np.concatenate([o, d, np.full((1, n), 0.001), np.full((1, n), 1e5)]).astype(np.float32)
+
+
+def test_bvh_equals_bruteforce_fp32_and_tracks_fp64():
+    mesh = scenes.atrium(0.2)
+    sc = orc.Scene(mesh)
+    assert sc.n_nodes == sc.n_tris - 1 and sc.max_depth < 64
+    codes = sc.codes()
+    assert (np.diff(codes.astype(np.float64)) >= 0).all()  # Morton order
+    rays = random_rays(6000, 3, [-14, 0.2, -8], [14, 12, 8])
+    t, u, v, p, nn, nt = sc.trace_closest(rays, counts=True)
+    bt, bu, bv, bp = sc.trace_brute(rays, 0)
+    assert np.array_equal(p, bp) and np.array_equal(t, bt) and np.array_equal(u, bu) and np.array_equal(v, bv)
+    dt, du, dv, dp = sc.trace_brute(rays, 1)
+    # fp64 may pick another primitive where surfaces coincide (coplanar floor / plinth / slab faces: ties in t), so compare
+    # the hit distance; hit-vs-miss may flip only for grazing rays at silhouettes
+    both = (p != orc.MISS) & (dp != orc.MISS)
+    assert ((p != orc.MISS) == (dp != orc.MISS)).mean() > 0.999
+    assert np.quantile(np.abs(t[both] - dt[both]), 0.999) < 1e-3
+    assert (dp == p).mean() > 0.95
+    occ = sc.trace_any(rays)
+    assert np.array_equal(occ != 0, p != orc.MISS)
+    assert 5 < nn.mean() < 200 and nt.mean() < 20
+    hit = p != orc.MISS
+    assert (u[hit] >= 0).all() and (v[hit] >= 0).all() and (u[hit] + v[hit] <= 1).all() and (t[hit] > 0.001).all()
+
+
+def test_tmin_tmax_interval_and_ties():
+    from raytracer3_amd import assets
+
+    mb = assets.MeshBuilder()
+    tri = np.array([[-1, -1, 0], [1, -1, 0], [0, 1, 0]], np.float32)
+    for k in range(3):  # three coincident copies at z = 0 and one at z = 1
+        mb.add(f"c{k}", tri, np.tile([0, 0, 1], (3, 1)), None, [[0, 1, 2]], assets.Material())
+    mb.add("far", tri + [0, 0, 1], np.tile([0, 0, 1], (3, 1)), None, [[0, 1, 2]], assets.Material())
+    sc = orc.Scene(mb.build())
+    def ray(oz, dz, tmin, tmax):
+        return np.array([[0, 0, oz, 0, 0, dz, tmin, tmax]], np.float32).T.copy()
+    t, u, v, p = sc.trace_closest(ray(-1, 1, 0, 1e5))
+    assert p[0] == 0 and t[0] == 1.0  # tie at t = 1 -> lowest primitive id
+    t, u, v, p = sc.trace_closest(ray(-1, 1, 1.0, 1e5))
+    assert p[0] == 3 and t[0] == 2.0  # t must be > tmin: the coincident sheet at t == tmin is skipped
+    t, u, v, p = sc.trace_closest(ray(-1, 1, 0, 0.5))
+    assert p[0] == orc.MISS  # nothing inside (tmin, tmax)
+    t, u, v, p = sc.trace_closest(ray(2, -1, 0, 1e5))
+    assert p[0] == 3 and t[0] == 1.0  # back faces are hit too (no culling)
