@@ -61,6 +61,7 @@ struct rt3_ctx {
     uint32_t n_geoms = 0, n_prims = 0;
     uint32_t *d_prim_geom = nullptr, *d_first_prim = nullptr;
     float *d_sky = nullptr, *d_cdf_cond = nullptr, *d_cdf_marg = nullptr, *d_pdf_uv = nullptr;
+    uint16_t *d_guide_cond = nullptr, *d_guide_marg = nullptr;
     uint32_t sky_w = 0, sky_h = 0;
     uint8_t* d_bn = nullptr;
     uint32_t bn_w = 0, bn_h = 0;
@@ -183,6 +184,9 @@ SceneDev scene_dev(const rt3_ctx* c) {
     s.geoms = c->d_geoms;
     s.prim_geom = c->d_prim_geom;
     s.first_prim = c->d_first_prim;
+    s.tri_shade = c->bvh.tri_shade;
+    s.guide_cond = c->d_guide_cond;
+    s.guide_marg = c->d_guide_marg;
     s.sky = c->d_sky;
     s.cdf_cond = c->d_cdf_cond;
     s.cdf_marg = c->d_cdf_marg;
@@ -470,7 +474,7 @@ void rt3_destroy(rt3_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dev_free(c->d_verts); dev_free(c->d_indices); dev_free(c->d_geoms); dev_free(c->d_prim_geom); dev_free(c->d_first_prim);
     dev_free(c->d_sky); dev_free(c->d_cdf_cond); dev_free(c->d_cdf_marg); dev_free(c->d_pdf_uv); dev_free(c->d_bn);
-    dev_free(c->bvh.nodes); dev_free(c->bvh.tris);
+    dev_free(c->bvh.nodes); dev_free(c->bvh.tris); dev_free(c->bvh.tri_shade); dev_free(c->d_guide_cond); dev_free(c->d_guide_marg);
     for (auto& r : c->resources)
         if (r.owned && r.ptr) (void)hipFree(r.ptr);
     for (auto& p : c->pixlists) (void)hipFree(p.dev);
@@ -562,6 +566,7 @@ int rt3_scene_set_geometry(rt3_ctx* c, const rt3_geometry_info* g, const uint32_
 // rows, pdf in (u,v).  Accumulated in double on the host, stored as float.
 int rt3_scene_set_sky(rt3_ctx* c, const float* rgb, uint32_t w, uint32_t h) {
     if (!c || !rgb || !w || !h) return fail(c, RT3_E_INVALID, "sky NULL / empty");
+    if (w > 65535 || h > 65535) return fail(c, RT3_E_INVALID, "sky larger than 65535 texels per side");
     HIPC(c, hipSetDevice(c->device));
     const size_t n = (size_t)w * h;
     std::vector<float> cond(n), pdf(n), marg(h);
@@ -592,6 +597,22 @@ int rt3_scene_set_sky(rt3_ctx* c, const float* rgb, uint32_t w, uint32_t h) {
     marg[h - 1] = 1.0f;
     const float norm = (float)((double)w * (double)h / total);
     for (size_t i = 0; i < n; i++) pdf[i] *= norm;
+    // guide tables: guide[k] = first index with cdf > k / n, so a lookup starts within one cell of its answer
+    auto build_guide = [](const float* cdf, uint32_t cnt, uint16_t* g) {
+        uint32_t i = 0;
+        for (uint32_t k = 0; k <= cnt; k++) {
+            const float thr = (float)k / (float)cnt;
+            while (i < cnt - 1 && !(cdf[i] > thr)) i++;
+            g[k] = (uint16_t)i;
+        }
+    };
+    std::vector<uint16_t> gcond((size_t)h * (w + 1)), gmarg(h + 1);
+    for (uint32_t y = 0; y < h; y++) build_guide(cond.data() + (size_t)y * w, w, gcond.data() + (size_t)y * (w + 1));
+    build_guide(marg.data(), h, gmarg.data());
+    if (int r = dev_alloc(c, &c->d_guide_cond, gcond.size())) return r;
+    if (int r = dev_alloc(c, &c->d_guide_marg, gmarg.size())) return r;
+    HIPC(c, hipMemcpy(c->d_guide_cond, gcond.data(), gcond.size() * 2, hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(c->d_guide_marg, gmarg.data(), gmarg.size() * 2, hipMemcpyHostToDevice));
     if (int r = dev_alloc(c, &c->d_sky, 3 * n)) return r;
     if (int r = dev_alloc(c, &c->d_cdf_cond, n)) return r;
     if (int r = dev_alloc(c, &c->d_pdf_uv, n)) return r;
@@ -630,11 +651,13 @@ int rt3_accel_build(rt3_ctx* c, uint32_t* out_handle) {
     HIPC(c, hipStreamSynchronize(c->stream));
     dev_free(c->bvh.nodes);
     dev_free(c->bvh.tris);
+    dev_free(c->bvh.tri_shade);
     hipError_t e = lbvh_build(c->stream, c->d_verts, c->d_indices, c->d_geoms, c->d_prim_geom, c->d_first_prim, c->n_prims, &c->bvh);
     if (e != hipSuccess) return fail(c, RT3_E_HIP, std::string("lbvh_build: ") + hipGetErrorString(e));
     if (c->bvh.max_depth > kMaxBvhDepth) {
         dev_free(c->bvh.nodes);
         dev_free(c->bvh.tris);
+        dev_free(c->bvh.tri_shade);
         return fail(c, RT3_E_DEPTH, "LBVH depth " + std::to_string(c->bvh.max_depth) + " exceeds the traversal stack (" + std::to_string(kMaxBvhDepth) + ")");
     }
     c->accel_built = true;

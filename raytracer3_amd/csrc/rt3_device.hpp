@@ -257,26 +257,27 @@ struct SceneDev {
     const GeometryInfoDev* geoms;
     const uint32_t* prim_geom;   // global primitive -> geometry
     const uint32_t* first_prim;  // geometry -> first global primitive
+    const float4* tri_shade;     // per global primitive, 64 B: {n0.xyz,n1.x} {n1.yz,n2.xy} {n2.z,geometry,-,-} {-}: one cache line
     // sky
     const float* sky;            // rgb
     const float* cdf_cond;
     const float* cdf_marg;
     const float* pdf_uv;
+    const uint16_t* guide_cond;  // per row, sky_w + 1 entries: guide_cond[k] = first x with cdf_cond[x] > k / sky_w
+    const uint16_t* guide_marg;  // sky_h + 1 entries
     uint32_t sky_w, sky_h;
     const uint8_t* bluenoise;
     uint32_t bn_w, bn_h;
 };
 
-// hit_logic.slang:5-40 (transform = identity, vertex colour = 1, no textures)
+// hit_logic.slang:5-40 (transform = identity, vertex colour = 1, no textures).  The three index + three vertex gathers of
+// :10-20 are folded at build time into one 64-byte shading record per primitive (same values, one cache line).
 RT3_DEV Surface hit_info(const SceneDev& sc, uint32_t prim, float bu, float bv) {
-    uint32_t g = sc.prim_geom[prim];
-    const GeometryInfoDev& gi = sc.geoms[g];
-    uint32_t io = gi.index_offset + 3u * (prim - sc.first_prim[g]);
-    const float* v0 = sc.verts + 8 * (size_t)(gi.vertex_offset + sc.indices[io]);
-    const float* v1 = sc.verts + 8 * (size_t)(gi.vertex_offset + sc.indices[io + 1]);
-    const float* v2 = sc.verts + 8 * (size_t)(gi.vertex_offset + sc.indices[io + 2]);
+    const float4* rec = sc.tri_shade + 4 * (size_t)prim;
+    float4 a = rec[0], b = rec[1], c = rec[2];
+    const GeometryInfoDev& gi = sc.geoms[__float_as_uint(c.y)];
     float b0 = 1.0f - bu - bv;
-    V3 n = v3(v0[3] * b0 + v1[3] * bu + v2[3] * bv, v0[4] * b0 + v1[4] * bu + v2[4] * bv, v0[5] * b0 + v1[5] * bu + v2[5] * bv);
+    V3 n = v3(a.x * b0 + a.w * bu + b.z * bv, a.y * b0 + b.x * bu + b.w * bv, a.z * b0 + b.y * bu + c.x * bv);
     n = normalize(normalize(n));  // :24 and :25
     Surface s;
     s.albedo = v3(gi.base_color[0], gi.base_color[1], gi.base_color[2]);
@@ -331,13 +332,27 @@ RT3_DEV uint32_t cdf_find(const float* cdf, uint32_t n, float u) {  // first ind
     }
     return lo;
 }
+// same result as cdf_find, but the search starts from a guide table (guide[k] = cdf_find(k / n)): u lies in cell
+// k = floor(u n), so the answer is inside [guide[k-1], guide[k+1]] (one cell of slack for the rounding of u n).
+RT3_DEV uint32_t cdf_find_guided(const float* cdf, const uint16_t* guide, uint32_t n, float u) {
+    uint32_t k = (uint32_t)(u * (float)n);
+    k = k > n - 1 ? n - 1 : k;
+    uint32_t lo = guide[k > 0 ? k - 1 : 0], hi = guide[k + 1];
+    hi = hi > n - 1 ? n - 1 : hi;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (cdf[mid] > u) hi = mid;
+        else lo = mid + 1;
+    }
+    return lo;
+}
 RT3_DEV void sky_sample(const SceneDev& sc, float u0, float u1, V3& dir, V3& rad, float& pdf) {
     uint32_t W = sc.sky_w, H = sc.sky_h;
-    uint32_t y = cdf_find(sc.cdf_marg, H, u0);
+    uint32_t y = cdf_find_guided(sc.cdf_marg, sc.guide_marg, H, u0);
     float lo = y > 0 ? sc.cdf_marg[y - 1] : 0.0f, hi = sc.cdf_marg[y];
     float dv = hi > lo ? (u0 - lo) / (hi - lo) : 0.5f;
     const float* row = sc.cdf_cond + (size_t)y * W;
-    uint32_t x = cdf_find(row, W, u1);
+    uint32_t x = cdf_find_guided(row, sc.guide_cond + (size_t)y * (W + 1), W, u1);
     lo = x > 0 ? row[x - 1] : 0.0f;
     hi = row[x];
     float du = hi > lo ? (u1 - lo) / (hi - lo) : 0.5f;

@@ -69,6 +69,7 @@ void launch_selftest(hipStream_t st, int op, const uint32_t* in, uint32_t n, uin
 struct LbvhResult {
     float4* nodes = nullptr;   // n_nodes x 4 float4 (64 B)
     float4* tris = nullptr;    // n_tris x 3 float4 (48 B), Morton order
+    float4* tri_shade = nullptr;  // n_tris x 4 float4 (64 B), global primitive order: vertex normals + geometry index
     uint32_t n_nodes = 0, n_tris = 0, max_depth = 0;
 };
 hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,

@@ -178,16 +178,46 @@ __global__ void k_gbuffer(SceneDev sc, const uint32_t* __restrict__ pixels, uint
 }
 
 // ------------------------------------------------------------------------------------------------ shading
-// wave-level queue append: one atomic per wave, order-preserving inside the wave
-__device__ __forceinline__ uint32_t wave_append(bool want, uint32_t* counter) {
-    unsigned long long mask = __ballot(want);
-    if (mask == 0ull) return 0u;
-    uint32_t lane = __lane_id();
-    uint32_t base = 0;
-    int leader = __ffsll((long long)mask) - 1;
-    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader);
-    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+// Queue append for a whole workgroup: every wave ballots its lanes, the wave totals meet in LDS and ONE returning
+// atomic per workgroup and queue reserves the range (a single counter word sustains only ~88 returning atomics per
+// microsecond chip-wide, so one atomic per wave made k_shade atomic-bound: 1 M atomics per launch ~ 10 ms).
+// Order is preserved inside the workgroup.  Must be reached by all threads of the block.
+constexpr int kShadeBlock = 512;
+struct BlockAppend {
+    uint32_t ext, sh;
+};
+__device__ __forceinline__ BlockAppend block_append2(bool want_ext, uint32_t* ext_counter, bool want_sh, uint32_t* sh_counter,
+                                                     uint32_t* lds /* 2 * (waves + 1) words */) {
+    constexpr int kWaves = kShadeBlock / 64;
+    const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
+    const unsigned long long m_ext = __ballot(want_ext), m_sh = __ballot(want_sh);
+    if (lane == 0) {
+        lds[wave] = (uint32_t)__popcll(m_ext);
+        lds[kWaves + 1 + wave] = (uint32_t)__popcll(m_sh);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t te = 0, ts = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; w++) {
+            uint32_t ce = lds[w], cs = lds[kWaves + 1 + w];
+            lds[w] = te;
+            lds[kWaves + 1 + w] = ts;
+            te += ce;
+            ts += cs;
+        }
+        uint32_t be = te ? atomicAdd(ext_counter, te) : 0u;
+        uint32_t bs = ts ? atomicAdd(sh_counter, ts) : 0u;
+        lds[kWaves] = be;
+        lds[2 * kWaves + 1] = bs;
+    }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    BlockAppend r;
+    r.ext = lds[kWaves] + lds[wave] + (uint32_t)__popcll(m_ext & below);
+    r.sh = lds[2 * kWaves + 1] + lds[kWaves + 1 + wave] + (uint32_t)__popcll(m_sh & below);
+    __syncthreads();  // lds is reused by the next loop iteration
+    return r;
 }
 
 struct ShadeArgs {
@@ -222,7 +252,8 @@ struct ShadeArgs {
 
 // refrence_mode.slang:28-57 for one bounce of every live path
 template <bool FIRST>
-__global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
+__global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
+    __shared__ uint32_t append_lds[2 * (kShadeBlock / 64 + 1)];
     const GConstDev& g = a.g;
     const uint32_t flags = g.pad[0], B = g.bounces, b = a.bounce;
     const uint32_t dims = flags ? 8u : 2u;
@@ -230,7 +261,7 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
     const bool bnz = (flags & RT3_FLAG_BLUENOISE) && a.sc.bluenoise != nullptr;
     const size_t S = a.stride;
     const uint32_t n = FIRST ? a.n_first : *a.in_count;
-    const uint32_t n_round = (n + 63u) & ~63u;  // whole waves iterate so that ballots see every lane
+    const uint32_t n_round = (n + (kShadeBlock - 1)) & ~(uint32_t)(kShadeBlock - 1);  // whole workgroups iterate: barriers inside
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
         bool active = i < n;
         uint32_t pid = 0;
@@ -252,10 +283,10 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
             if (active) {
                 size_t pi = (size_t)py * a.width + px;
                 float d0 = a.depth[pi];
-                a.lacc[pid] = 0.0f;
-                a.lacc[S + pid] = 0.0f;
-                a.lacc[2 * S + pid] = 0.0f;
                 if (d0 == kBackgroundDepth) {  // :18-21
+                    a.lacc[pid] = 0.0f;
+                    a.lacc[S + pid] = 0.0f;
+                    a.lacc[2 * S + pid] = 0.0f;
                     active = false;
                 } else {
                     surf = gbuffer_unpack(a.gbuffer[pi]);  // :23
@@ -306,10 +337,16 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
             build_orthonormal_basis(N, b1, b2);  // :44
             V3 wi = diffuse_sample(u0, u1);      // :45
             o = v3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);  // :47
-            // :50 radiance += ray_color * emissive
-            a.lacc[pid] += T.x * surf.emissive.x;
-            a.lacc[S + pid] += T.y * surf.emissive.y;
-            a.lacc[2 * S + pid] += T.z * surf.emissive.z;
+            // :50 radiance += ray_color * emissive.  x + (+0) == x exactly, so non-emitters skip the read-modify-write.
+            if (FIRST) {  // L starts at 0 and T = 1: 0 + 1 * e == e
+                a.lacc[pid] = T.x * surf.emissive.x;
+                a.lacc[S + pid] = T.y * surf.emissive.y;
+                a.lacc[2 * S + pid] = T.z * surf.emissive.z;
+            } else if (surf.emissive.x != 0.0f || surf.emissive.y != 0.0f || surf.emissive.z != 0.0f) {
+                a.lacc[pid] += T.x * surf.emissive.x;
+                a.lacc[S + pid] += T.y * surf.emissive.y;
+                a.lacc[2 * S + pid] += T.z * surf.emissive.z;
+            }
             if (nee) {
                 float ul0 = uniform_float(seed, base + 3), ul1 = uniform_float(seed, base + 4);
                 if (bnz) {
@@ -333,40 +370,37 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
             Tn = T * surf.albedo;             // :51
             emit_ext = b != B - 1;            // :53
         }
-        if (nee) {
-            uint32_t j = wave_append(emit_shadow, a.sh_count);
-            if (emit_shadow) {
-                a.sh_rays[j] = o.x;
-                a.sh_rays[S + j] = o.y;
-                a.sh_rays[2 * S + j] = o.z;
-                a.sh_rays[3 * S + j] = wl.x;
-                a.sh_rays[4 * S + j] = wl.y;
-                a.sh_rays[5 * S + j] = wl.z;
-                a.sh_rays[6 * S + j] = kRayTMin;
-                a.sh_rays[7 * S + j] = kBackgroundDepth;
-                a.sh_contrib[j] = contrib.x;
-                a.sh_contrib[S + j] = contrib.y;
-                a.sh_contrib[2 * S + j] = contrib.z;
-                a.sh_pid[j] = pid;
-            }
+        const BlockAppend slot = block_append2(emit_ext, a.out_count, emit_shadow, a.sh_count, append_lds);
+        if (emit_shadow) {
+            const uint32_t j = slot.sh;
+            a.sh_rays[j] = o.x;
+            a.sh_rays[S + j] = o.y;
+            a.sh_rays[2 * S + j] = o.z;
+            a.sh_rays[3 * S + j] = wl.x;
+            a.sh_rays[4 * S + j] = wl.y;
+            a.sh_rays[5 * S + j] = wl.z;
+            a.sh_rays[6 * S + j] = kRayTMin;
+            a.sh_rays[7 * S + j] = kBackgroundDepth;
+            a.sh_contrib[j] = contrib.x;
+            a.sh_contrib[S + j] = contrib.y;
+            a.sh_contrib[2 * S + j] = contrib.z;
+            a.sh_pid[j] = pid;
         }
-        if (b != B - 1) {
-            uint32_t j = wave_append(emit_ext, a.out_count);
-            if (emit_ext) {
-                a.out_rays[j] = o.x;
-                a.out_rays[S + j] = o.y;
-                a.out_rays[2 * S + j] = o.z;
-                a.out_rays[3 * S + j] = nd.x;
-                a.out_rays[4 * S + j] = nd.y;
-                a.out_rays[5 * S + j] = nd.z;
-                a.out_rays[6 * S + j] = kRayTMin;         // :31
-                a.out_rays[7 * S + j] = kBackgroundDepth;
-                a.out_T[j] = Tn.x;
-                a.out_T[S + j] = Tn.y;
-                a.out_T[2 * S + j] = Tn.z;
-                a.out_T[3 * S + j] = pdf_n;
-                a.out_pid[j] = pid;
-            }
+        if (emit_ext) {
+            const uint32_t j = slot.ext;
+            a.out_rays[j] = o.x;
+            a.out_rays[S + j] = o.y;
+            a.out_rays[2 * S + j] = o.z;
+            a.out_rays[3 * S + j] = nd.x;
+            a.out_rays[4 * S + j] = nd.y;
+            a.out_rays[5 * S + j] = nd.z;
+            a.out_rays[6 * S + j] = kRayTMin;         // :31
+            a.out_rays[7 * S + j] = kBackgroundDepth;
+            a.out_T[j] = Tn.x;
+            a.out_T[S + j] = Tn.y;
+            a.out_T[2 * S + j] = Tn.z;
+            a.out_T[3 * S + j] = pdf_n;
+            a.out_pid[j] = pid;
         }
     }
 }
@@ -588,9 +622,9 @@ void launch_shade(hipStream_t st, bool first, const ShadeLaunch& L) {
     a.out_rays = L.out_rays; a.out_T = L.out_T; a.out_pid = L.out_pid; a.out_count = L.out_count;
     a.sh_rays = L.sh_rays; a.sh_contrib = L.sh_contrib; a.sh_pid = L.sh_pid; a.sh_count = L.sh_count;
     a.lacc = L.lacc; a.stride = L.stride;
-    unsigned grid = grid_for(L.max_n, 256, 8192);
-    if (first) hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(256), 0, st, a);
+    unsigned grid = grid_for(L.max_n, kShadeBlock, 8192);
+    if (first) hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(kShadeBlock), 0, st, a);
+    else hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(kShadeBlock), 0, st, a);
 }
 void launch_accumulate(hipStream_t st, const GConstDev& g, const uint32_t* pixels, uint32_t npix, uint32_t width, const float* depth,
                        const float* lacc, size_t stride, uint32_t sb, int first_batch, int last_batch, float* radsum, void* light,

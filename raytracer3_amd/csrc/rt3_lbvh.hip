@@ -79,6 +79,23 @@ __global__ void k_prim_bounds(const float* verts, const uint32_t* indices, const
     }
 }
 
+// shading record of hit_logic.slang:10-25: the three vertex normals + the geometry index of each primitive, 64 B
+__global__ void k_tri_shade(const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,
+                            const uint32_t* first_prim, uint32_t n, float4* rec) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        uint32_t g = prim_geom[p];
+        const GeometryInfoDev& gi = geoms[g];
+        uint32_t io = gi.index_offset + 3u * (p - first_prim[g]);
+        const float* v0 = verts + 8 * (size_t)(gi.vertex_offset + indices[io]);
+        const float* v1 = verts + 8 * (size_t)(gi.vertex_offset + indices[io + 1]);
+        const float* v2 = verts + 8 * (size_t)(gi.vertex_offset + indices[io + 2]);
+        rec[4 * (size_t)p + 0] = make_float4(v0[3], v0[4], v0[5], v1[3]);
+        rec[4 * (size_t)p + 1] = make_float4(v1[4], v1[5], v2[3], v2[4]);
+        rec[4 * (size_t)p + 2] = make_float4(v2[5], __uint_as_float(g), 0.0f, 0.0f);
+        rec[4 * (size_t)p + 3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+}
+
 __device__ __forceinline__ uint64_t expand21(uint32_t v) {
     uint64_t x = v & 0x1FFFFFu;
     x = (x | (x << 32)) & 0x001F00000000FFFFull;
@@ -290,12 +307,14 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
     LB_CHECK(hipMalloc(&depth, 4));
     LB_CHECK(hipMalloc(&out->nodes, (size_t)nn * 64));
     LB_CHECK(hipMalloc(&out->tris, (size_t)n * 48));
+    LB_CHECK(hipMalloc(&out->tri_shade, (size_t)n * 64));
     out->n_nodes = nn;
     LB_CHECK(hipMemcpyAsync(bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, st));
     LB_CHECK(hipMemsetAsync(arrive, 0, (size_t)nn * 4, st));
     LB_CHECK(hipMemsetAsync(depth, 0, 4, st));
     LB_CHECK(hipMemsetAsync(out->nodes, 0, (size_t)nn * 64, st));
     hipLaunchKernelGGL(k_prim_bounds, dim3(grid), dim3(256), 0, st, verts, indices, geoms, prim_geom, first_prim, n, bmin, bmax, bounds);
+    hipLaunchKernelGGL(k_tri_shade, dim3(grid), dim3(256), 0, st, verts, indices, geoms, prim_geom, first_prim, n, out->tri_shade);
     hipLaunchKernelGGL(k_morton, dim3(grid), dim3(256), 0, st, bmin, bmax, bounds, n, keys_in, vals_in);
     LB_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, 63, st));
     LB_CHECK(hipMalloc(&temp, temp_bytes ? temp_bytes : 16));
@@ -320,8 +339,10 @@ done:
     if (err != hipSuccess) {
         (void)hipFree(out->nodes);
         (void)hipFree(out->tris);
+        (void)hipFree(out->tri_shade);
         out->nodes = nullptr;
         out->tris = nullptr;
+        out->tri_shade = nullptr;
     }
     return err;
 }
