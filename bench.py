@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--bounces", type=int, default=4)
     ap.add_argument("--detail", type=float, default=1.0)
     ap.add_argument("--batch-spp", type=int, default=0)
+    ap.add_argument("--leaf-size", type=int, default=0, help="triangles per BVH leaf (0 = library default)")
+    ap.add_argument("--node-width", type=int, default=0, help="2 | 4 (0 = library default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-crop", type=str, default="960x540")
     args = ap.parse_args()
@@ -70,6 +72,10 @@ def main():
     sky = scenes.sky(2048, 1024)
     bn = assets.load_bluenoise()
     pt = PathTracer((W, H), device=local_rank, rank=rank, n_ranks=world)
+    if args.leaf_size:
+        pt.ctx.set_option(L.OPT_LEAF_SIZE, args.leaf_size)
+    if args.node_width:
+        pt.ctx.set_option(L.OPT_NODE_WIDTH, args.node_width)
     pt.set_scene(mesh, sky, bn)
     if args.batch_spp:
         pt.ctx.set_option(L.OPT_BATCH_SPP, args.batch_spp)
@@ -116,8 +122,9 @@ def main():
     pt.render(g_last, postprocess=False, wait=True)
     cst = pt.ctx.stats()
     pt.ctx.set_option(L.OPT_COUNT_TRAVERSAL, 0)
-    bytes_per_frame = 48.0 * cst.extension_rays + 64.0 * cst.nodes_visited + 48.0 * cst.tris_tested
-    sh_bytes_per_frame = 48.0 * cst.shadow_rays + 64.0 * cst.shadow_nodes_visited + 48.0 * cst.shadow_tris_tested
+    n_nodes, n_tris, levels, node_bytes = pt.ctx.accel_info()
+    bytes_per_frame = 48.0 * cst.extension_rays + float(node_bytes) * cst.nodes_visited + 48.0 * cst.tris_tested
+    sh_bytes_per_frame = 48.0 * cst.shadow_rays + float(node_bytes) * cst.shadow_nodes_visited + 48.0 * cst.shadow_tris_tested
     ext_ms_per_frame = st.extend_ms / max(args.steps, 1)
     launches_per_frame = st.extend_launches / max(args.steps, 1)
     achieved = bytes_per_frame / (ext_ms_per_frame * 1e-3) / 1e9 if ext_ms_per_frame > 0 else 0.0
@@ -127,6 +134,7 @@ def main():
         "traffic": None,  # HBM bytes from rocprofv3 PMC passes: see profiles/ and DESIGN.md (not collectable inside bench.py)
         "launches_per_frame": launches_per_frame, "avg_launch_ms": round(ext_ms_per_frame / max(launches_per_frame, 1), 4),
         "algorithmic_bytes_per_launch": round(bytes_per_frame / max(launches_per_frame, 1)),
+        "bytes_per_ray_formula": f"48 + {node_bytes}*n_nodes + 48*n_tris", "bvh": {"nodes": n_nodes, "node_bytes": node_bytes, "tris": n_tris, "levels": levels},
         "rays_per_frame": int(cst.extension_rays), "nodes_per_ray": round(cst.nodes_visited / max(cst.extension_rays, 1), 2),
         "tris_per_ray": round(cst.tris_tested / max(cst.extension_rays, 1), 2),
         "k_shadow": {"achieved": round(sh_bytes_per_frame / max(st.shadow_ms / max(args.steps, 1) * 1e-3, 1e-12) / 1e9, 1),
@@ -155,7 +163,7 @@ def main():
         x0, y0 = (W - cw) // 2, (H - ch) // 2
         rect = (x0, y0, x0 + cw, y0 + ch)
         threads = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 256)
-        osc = orc.Scene(mesh, sky, bn)
+        osc = orc.Scene(mesh, sky, bn, leaf_size=args.leaf_size or 2, node_width=args.node_width or 4)
         og = orc.GConst()
         C.memmove(C.byref(og), C.byref(g_last), 304)
         ogb, odepth = osc.gbuffer(og, rect=rect, threads=threads)

@@ -110,6 +110,8 @@ int rt3_device_name(rt3_ctx *ctx, char *buf, size_t buf_size);
 #define RT3_OPT_PROFILE 2         /* 1: bracket kernels with HIP events on the context's stream */
 #define RT3_OPT_COUNT_TRAVERSAL 3 /* 1: k_extend/k_shadow also count nodes / triangles (slower; for roofline bytes) */
 #define RT3_OPT_EXTEND_VARIANT 4  /* traversal kernel variant (0 = default) */
+#define RT3_OPT_LEAF_SIZE 5       /* 1..8 triangles per BVH leaf (default 2); takes effect at the next rt3_accel_build */
+#define RT3_OPT_NODE_WIDTH 6      /* 2 = 64 B binary nodes, 4 = 128 B four-wide nodes (default); next rt3_accel_build */
 int rt3_set_option(rt3_ctx *ctx, int option, int64_t value);
 
 /* ---- scene upload: DynamicBuffer::push (vulkan/buffer.rs:406-420) into the world buffers of
@@ -123,8 +125,8 @@ int rt3_scene_set_bluenoise(rt3_ctx *ctx, const uint8_t *rgba, uint32_t width, u
 /* ---- acceleration structure: create_acceleration_structure (vulkan/raytracing.rs:88-148) -> GPU LBVH.
  *      Returns the handle (tag 3) in *out_handle, like the TLAS registered at bindless/mod.rs:314-337 ---- */
 int rt3_accel_build(rt3_ctx *ctx, uint32_t *out_handle);
-/* introspection for parity tests: copy the BVH to the host (nodes: n_nodes x 64 B, tris: n_tris x 48 B) */
-int rt3_accel_info(rt3_ctx *ctx, uint32_t *n_nodes, uint32_t *n_tris, uint32_t *max_depth);
+/* introspection for parity tests: copy the BVH to the host (nodes: n_nodes x node_bytes (64 | 128), tris: n_tris x 48 B) */
+int rt3_accel_info(rt3_ctx *ctx, uint32_t *n_nodes, uint32_t *n_tris, uint32_t *max_depth, uint32_t *node_bytes);
 int rt3_accel_download(rt3_ctx *ctx, void *nodes, size_t nodes_bytes, void *tris, size_t tris_bytes);
 int rt3_sky_download(rt3_ctx *ctx, float *cdf_cond, float *cdf_marg, float *pdf_uv); /* w*h, h, w*h floats */
 

@@ -403,7 +403,7 @@ struct orc_scene {
     orc_geometry_info *geoms; uint32_t *prim_counts, *first_prim; uint32_t n_geoms;
     uint32_t n_prims; uint32_t *prim_geom;
     /* accel */
-    uint32_t n_tris, n_nodes, max_depth;
+    uint32_t n_tris, n_nodes, max_depth, leaf_max, node_width;
     float *nodes;   /* 16 words per node */
     float *tris;    /* 12 words per tri (Morton order) */
     uint64_t *codes;
@@ -414,7 +414,18 @@ struct orc_scene {
     uint8_t *bn; uint32_t bn_w, bn_h;
 };
 
-orc_scene *orc_scene_create(void) { return (orc_scene *)calloc(1, sizeof(orc_scene)); }
+orc_scene *orc_scene_create(void) {
+    orc_scene *s = (orc_scene *)calloc(1, sizeof(orc_scene));
+    s->leaf_max = 2;
+    s->node_width = 4;
+    return s;
+}
+/* leaf_max: 1..8 triangles per leaf; node_width: 2 (64 B nodes) or 4 (128 B nodes).  Call before orc_accel_build. */
+void orc_accel_set_layout(orc_scene *s, uint32_t leaf_max, uint32_t node_width) {
+    s->leaf_max = leaf_max < 1 ? 1 : (leaf_max > 8 ? 8 : leaf_max);
+    s->node_width = node_width == 2 ? 2 : 4;
+}
+uint32_t orc_accel_node_words(const orc_scene *s) { return s->node_width == 2 ? 16u : 32u; }
 static void accel_free(orc_scene *s) {
     free(s->nodes); free(s->tris); free(s->codes);
     s->nodes = s->tris = NULL; s->codes = NULL; s->n_tris = s->n_nodes = 0;
@@ -590,14 +601,19 @@ int orc_accel_build(orc_scene *s) {
     }
     uint32_t nn = n > 1 ? n - 1 : 1;
     s->n_nodes = nn;
-    s->nodes = (float *)calloc((size_t)nn * 16, 4);
-    if (n == 1) {
+    if (n == 1) { /* root with the single leaf in slot 0, the other slots empty */
+        const uint32_t W4 = s->node_width == 4, words = W4 ? 32u : 16u;
+        s->nodes = (float *)calloc(words, 4);
         float *nd = s->nodes;
-        for (int j = 0; j < 3; j++) { nd[j] = lmin[j]; nd[3 + j] = lmax[j]; nd[6 + j] = INFINITY; nd[9 + j] = -INFINITY; }
-        nd[12] = u2f(0x80000000u); nd[13] = u2f(0x80000000u);
-        s->max_depth = 1;
+        for (uint32_t k = 0; k < (W4 ? 4u : 2u); k++) {
+            float *mn = W4 ? nd + 8 * k : nd + 6 * k, *mx = mn + 3;
+            for (int j = 0; j < 3; j++) { mn[j] = k ? INFINITY : lmin[j]; mx[j] = k ? -INFINITY : lmax[j]; }
+            if (W4) nd[8 * k + 6] = u2f(k ? 0xFFFFFFFFu : 0x80000000u); else nd[12 + k] = u2f(k ? 0xFFFFFFFFu : 0x80000000u);
+        }
+        s->max_depth = 2;
     } else {
-        int32_t *left = (int32_t *)malloc((size_t)nn * 4), *right = (int32_t *)malloc((size_t)nn * 4);
+        uint32_t *left = (uint32_t *)malloc((size_t)nn * 4), *right = (uint32_t *)malloc((size_t)nn * 4);
+        uint32_t *rlo = (uint32_t *)malloc((size_t)nn * 4), *rcnt = (uint32_t *)malloc((size_t)nn * 4);
         const uint64_t *codes = s->codes;
         int N = (int)n;
         for (int i = 0; i < N - 1; i++) { /* Karras 2012, Algorithm "construct internal node i" */
@@ -617,41 +633,76 @@ int orc_accel_build(orc_scene *s) {
             } while (t > 1);
             int gamma = i + sp * d + (d < 0 ? d : 0);
             int lo = i < j ? i : j, hi = i < j ? j : i;
-            left[i] = (lo == gamma) ? (int32_t)(0x80000000u | (uint32_t)gamma) : gamma;
-            right[i] = (hi == gamma + 1) ? (int32_t)(0x80000000u | (uint32_t)(gamma + 1)) : gamma + 1;
+            left[i] = (lo == gamma) ? (0x80000000u | (uint32_t)gamma) : (uint32_t)gamma;
+            right[i] = (hi == gamma + 1) ? (0x80000000u | (uint32_t)(gamma + 1)) : (uint32_t)(gamma + 1);
+            rlo[i] = (uint32_t)lo; rcnt[i] = (uint32_t)(hi - lo + 1);
         }
-        /* boxes: iterative post-order from the root (node 0) */
+        /* boxes of every binary node (post-order from the root) and its binary depth (root = 0) */
         float *nmin = (float *)malloc((size_t)nn * 12), *nmax = (float *)malloc((size_t)nn * 12);
         uint32_t *stack = (uint32_t *)malloc((size_t)nn * 2 * 4 + 64);
         uint8_t *state = (uint8_t *)calloc(nn, 1);
         uint32_t *depth = (uint32_t *)calloc(nn, 4);
         int sp = 0;
-        stack[sp++] = 0; depth[0] = 1;
-        uint32_t maxd = 1;
+        stack[sp++] = 0;
         while (sp > 0) {
             uint32_t i = stack[sp - 1];
+            uint32_t l = left[i], r = right[i];
             if (!state[i]) {
                 state[i] = 1;
-                uint32_t l = (uint32_t)left[i], r = (uint32_t)right[i];
                 if (!(l & 0x80000000u)) { depth[l] = depth[i] + 1; stack[sp++] = l; }
                 if (!(r & 0x80000000u)) { depth[r] = depth[i] + 1; stack[sp++] = r; }
-                if (depth[i] + 1 > maxd) maxd = depth[i] + 1;
             } else {
                 sp--;
-                uint32_t ch[2] = {(uint32_t)left[i], (uint32_t)right[i]};
-                float *nd = s->nodes + 16 * (size_t)i;
-                for (int c = 0; c < 2; c++) {
-                    const float *mn, *mx;
-                    if (ch[c] & 0x80000000u) { uint32_t k = ch[c] & 0x7FFFFFFFu; mn = lmin + 3 * k; mx = lmax + 3 * k; }
-                    else { mn = nmin + 3 * ch[c]; mx = nmax + 3 * ch[c]; }
-                    for (int j = 0; j < 3; j++) { nd[6 * c + j] = mn[j]; nd[6 * c + 3 + j] = mx[j]; }
-                    nd[12 + c] = u2f(ch[c]);
-                }
-                for (int j = 0; j < 3; j++) { nmin[3 * i + j] = fminx(nd[j], nd[6 + j]); nmax[3 * i + j] = fmaxx(nd[3 + j], nd[9 + j]); }
+                const float *amn = (l & 0x80000000u) ? lmin + 3 * (l & 0x7FFFFFFFu) : nmin + 3 * l, *amx = (l & 0x80000000u) ? lmax + 3 * (l & 0x7FFFFFFFu) : nmax + 3 * l;
+                const float *bmn = (r & 0x80000000u) ? lmin + 3 * (r & 0x7FFFFFFFu) : nmin + 3 * r, *bmx = (r & 0x80000000u) ? lmax + 3 * (r & 0x7FFFFFFFu) : nmax + 3 * r;
+                for (int j = 0; j < 3; j++) { nmin[3 * i + j] = fminx(amn[j], bmn[j]); nmax[3 * i + j] = fmaxx(amx[j], bmx[j]); }
             }
         }
+        /* Multi-triangle leaves: an internal node covering <= leaf_max triangles (contiguous in Morton order) is referenced
+         * as a leaf {bit 31, count-1 in bits 30..28, first triangle in bits 27..0}; the root always stays a node.
+         * Wide nodes (node_width 4): the nodes at even binary depth survive and absorb their internal children, so each
+         * holds 2..4 child slots {min, max, ref, pad} of 32 B = one 128 B cache line; empty slots carry ref 0xFFFFFFFF.
+         * Surviving nodes are renumbered densely in index order (an exclusive scan on the GPU). */
+        const uint32_t K = s->leaf_max, W4 = s->node_width == 4;
+#define ORC_LIVE(i) ((i) == 0 || rcnt[i] > K)
+#define ORC_KEEP(i) (ORC_LIVE(i) && (!W4 || (depth[i] & 1u) == 0))
+        uint32_t *newidx = (uint32_t *)malloc((size_t)nn * 4), kept = 0, maxd = 0;
+        for (uint32_t i = 0; i < nn; i++) { newidx[i] = kept; if (ORC_KEEP(i)) kept++; }
+        const uint32_t words = W4 ? 32u : 16u;
+        free(s->nodes);
+        s->nodes = (float *)calloc((size_t)kept * words, 4);
+        for (uint32_t i = 0; i < nn; i++) {
+            if (!ORC_KEEP(i)) continue;
+            uint32_t slots[4], ns = 0, c2[2] = {left[i], right[i]};
+            for (int c = 0; c < 2; c++) {
+                uint32_t ch = c2[c];
+                if (W4 && !(ch & 0x80000000u) && ORC_LIVE(ch)) { slots[ns++] = left[ch]; slots[ns++] = right[ch]; } /* absorbed */
+                else slots[ns++] = ch;
+            }
+            float *nd = s->nodes + (size_t)words * newidx[i];
+            for (uint32_t k = 0; k < (W4 ? 4u : 2u); k++) {
+                float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+                uint32_t ref = 0xFFFFFFFFu;
+                if (k < ns) {
+                    uint32_t ch = slots[k];
+                    if (ch & 0x80000000u) { uint32_t q = ch & 0x7FFFFFFFu; ref = 0x80000000u | q; memcpy(mn, lmin + 3 * q, 12); memcpy(mx, lmax + 3 * q, 12); }
+                    else {
+                        memcpy(mn, nmin + 3 * ch, 12); memcpy(mx, nmax + 3 * ch, 12);
+                        ref = ORC_LIVE(ch) ? newidx[ch] : (0x80000000u | ((rcnt[ch] - 1u) << 28) | rlo[ch]);
+                    }
+                }
+                if (W4) { memcpy(nd + 8 * k, mn, 12); memcpy(nd + 8 * k + 3, mx, 12); nd[8 * k + 6] = u2f(ref); nd[8 * k + 7] = 0.0f; }
+                else { memcpy(nd + 6 * k, mn, 12); memcpy(nd + 6 * k + 3, mx, 12); nd[12 + k] = u2f(ref); }
+            }
+            uint32_t lvl = (W4 ? depth[i] / 2u : depth[i]) + 2u; /* levels from the root to this node's leaf slots */
+            if (!W4) { /* binary: collapsed ancestors do not exist, every live ancestor is a level */ }
+            if (lvl > maxd) maxd = lvl;
+        }
         s->max_depth = maxd;
-        free(left); free(right); free(nmin); free(nmax); free(stack); free(state); free(depth);
+        s->n_nodes = kept;
+#undef ORC_LIVE
+#undef ORC_KEEP
+        free(left); free(right); free(rlo); free(rcnt); free(nmin); free(nmax); free(stack); free(state); free(depth); free(newidx);
     }
     free(bmin); free(bmax); free(cp); free(lmin); free(lmax);
     return 0;
@@ -703,7 +754,9 @@ static inline int slab(const float *bx, const float o[3], const float inv[3], fl
     return tn <= tf;
 }
 #define ORC_STACK 256
-/* closest hit; near child first (ties: child 0), far child pushed, no re-cull on pop */
+#define ORC_EMPTY 0xFFFFFFFFu
+/* Closest / any hit.  Children are visited nearest first (ties: lower slot), the others are pushed so that they pop in
+ * ascending entry distance; no re-cull on pop.  A leaf reference holds 1..8 triangles, tested in order. */
 static void traverse(const orc_scene *s, const float o[3], const float d[3], float tmin, float tmax, int any,
                      hit_t *out, uint32_t *cn, uint32_t *ct) {
     hit_t best = {tmax, 0.0f, 0.0f, ORC_MISS};
@@ -712,27 +765,44 @@ static void traverse(const orc_scene *s, const float o[3], const float d[3], flo
         float inv[3] = {guard_inv(d[0]), guard_inv(d[1]), guard_inv(d[2])};
         uint32_t stack[ORC_STACK]; int sp = 0;
         uint32_t cur = 0;
+        const int W4 = s->node_width == 4;
         for (;;) {
             if (cur & 0x80000000u) {
-                nt++;
-                tri_test(s->tris + 12 * (size_t)(cur & 0x7FFFFFFFu), o, d, tmin, &best);
+                uint32_t first = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u, k;
+                for (k = 0; k < cnt; k++) {
+                    nt++;
+                    tri_test(s->tris + 12 * (size_t)(first + k), o, d, tmin, &best);
+                    if (any && best.prim != ORC_MISS) break;
+                }
                 if (any && best.prim != ORC_MISS) break;
                 if (sp == 0) break;
                 cur = stack[--sp];
                 continue;
             }
-            const float *nd = s->nodes + 16 * (size_t)cur;
             nn++;
-            float tn0, tn1;
-            int h0 = slab(nd, o, inv, tmin, best.t, &tn0), h1 = slab(nd + 6, o, inv, tmin, best.t, &tn1);
-            uint32_t r0 = f2u(nd[12]), r1 = f2u(nd[13]);
-            if (h0 && h1) {
-                int near1 = tn1 < tn0;
-                stack[sp++] = near1 ? r0 : r1;
-                cur = near1 ? r1 : r0;
-            } else if (h0) cur = r0;
-            else if (h1) cur = r1;
-            else { if (sp == 0) break; cur = stack[--sp]; }
+            uint32_t ref[4]; float tn[4]; int nh = 0;
+            if (W4) {
+                const float *nd = s->nodes + 32 * (size_t)cur;
+                for (int k = 0; k < 4; k++) {
+                    uint32_t r = f2u(nd[8 * k + 6]); float t;
+                    if (r != ORC_EMPTY && slab(nd + 8 * k, o, inv, tmin, best.t, &t)) {
+                        int p = nh++;
+                        while (p > 0 && t < tn[p - 1]) { tn[p] = tn[p - 1]; ref[p] = ref[p - 1]; p--; } /* stable: ties keep slot order */
+                        tn[p] = t; ref[p] = r;
+                    }
+                }
+            } else {
+                const float *nd = s->nodes + 16 * (size_t)cur;
+                float t0, t1;
+                uint32_t r0 = f2u(nd[12]), r1 = f2u(nd[13]);
+                int h0 = r0 != ORC_EMPTY && slab(nd, o, inv, tmin, best.t, &t0), h1 = r1 != ORC_EMPTY && slab(nd + 6, o, inv, tmin, best.t, &t1);
+                if (h0 && h1) { int near1 = t1 < t0; ref[0] = near1 ? r1 : r0; ref[1] = near1 ? r0 : r1; nh = 2; }
+                else if (h0) { ref[0] = r0; nh = 1; }
+                else if (h1) { ref[0] = r1; nh = 1; }
+            }
+            if (nh == 0) { if (sp == 0) break; cur = stack[--sp]; continue; }
+            for (int k = nh - 1; k >= 1; k--) stack[sp++] = ref[k];
+            cur = ref[0];
         }
     }
     *out = best;

@@ -102,10 +102,13 @@ int orc_scene_set_geometry(orc_scene *s, const orc_geometry_info *g, const uint3
 int orc_scene_set_sky(orc_scene *s, const float *rgb, uint32_t w, uint32_t h);
 int orc_scene_set_bluenoise(orc_scene *s, const uint8_t *rgba, uint32_t w, uint32_t h);
 /* LBVH (Karras 2012) over all triangles; replaces raytracing.rs:88-148 */
+/* leaf_max 1..8 triangles per leaf (default 2); node_width 2 = 64 B binary nodes, 4 = 128 B four-wide nodes (default) */
+void orc_accel_set_layout(orc_scene *s, uint32_t leaf_max, uint32_t node_width);
+uint32_t orc_accel_node_words(const orc_scene *s);
 int orc_accel_build(orc_scene *s);
 uint32_t orc_accel_num_tris(const orc_scene *s);
 uint32_t orc_accel_num_nodes(const orc_scene *s);
-const float *orc_accel_nodes(const orc_scene *s);  /* n_nodes x 16 words (64 B)  */
+const float *orc_accel_nodes(const orc_scene *s);  /* n_nodes x orc_accel_node_words() 32-bit words */
 const float *orc_accel_tris(const orc_scene *s);   /* n_tris  x 12 words (48 B), Morton order */
 const uint64_t *orc_accel_codes(const orc_scene *s);
 uint32_t orc_accel_max_depth(const orc_scene *s);

@@ -86,6 +86,7 @@ struct rt3_ctx {
     int64_t opt_batch_spp = 0;
     bool opt_profile = false, opt_count = false;
     int opt_variant = 0;
+    uint32_t opt_leaf_size = 2, opt_node_width = 4;
     rt3_stats stats;
     uint64_t primary_rays_pending = 0;
     std::vector<Timed> pending_events;
@@ -333,7 +334,7 @@ int pass_gbuffer(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y, const 
     }
     {
         ScopedTimer t(c, CAT_EXTEND);
-        launch_extend(c->stream, c->opt_count, c->bvh.nodes, c->bvh.tris, c->rays[0], S, nullptr, pl->count, pl->count, c->hits, nullptr, nullptr,
+        launch_extend(c->stream, c->opt_count, c->bvh.node_bytes == 128, c->bvh.nodes, c->bvh.tris, c->rays[0], S, nullptr, pl->count, pl->count, c->hits, nullptr, nullptr,
                       c->opt_count ? c->d_totals : nullptr);
     }
     c->primary_rays_pending += pl->count;
@@ -399,12 +400,12 @@ int pass_reference_mode(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y,
             cur ^= 1;
             if (nee) {
                 ScopedTimer t(c, CAT_SHADOW);
-                launch_shadow(c->stream, c->opt_count, c->bvh.nodes, c->bvh.tris, c->sh_rays, S, sh_cnt + bn, 0, n_first, c->sh_contrib, c->sh_pid,
+                launch_shadow(c->stream, c->opt_count, c->bvh.node_bytes == 128, c->bvh.nodes, c->bvh.tris, c->sh_rays, S, sh_cnt + bn, 0, n_first, c->sh_contrib, c->sh_pid,
                               c->lacc, S, nullptr, nullptr, nullptr, c->opt_count ? c->d_totals + 2 : nullptr);
             }
             if (bn != B - 1) {
                 ScopedTimer t(c, CAT_EXTEND);
-                launch_extend(c->stream, c->opt_count, c->bvh.nodes, c->bvh.tris, c->rays[cur], S, ext_cnt + bn, 0, n_first, c->hits, nullptr, nullptr,
+                launch_extend(c->stream, c->opt_count, c->bvh.node_bytes == 128, c->bvh.nodes, c->bvh.tris, c->rays[cur], S, ext_cnt + bn, 0, n_first, c->hits, nullptr, nullptr,
                               c->opt_count ? c->d_totals : nullptr);
             }
         }
@@ -502,6 +503,16 @@ int rt3_set_option(rt3_ctx* c, int option, int64_t value) {
         case RT3_OPT_PROFILE: c->opt_profile = value != 0; return RT3_OK;
         case RT3_OPT_COUNT_TRAVERSAL: c->opt_count = value != 0; return RT3_OK;
         case RT3_OPT_EXTEND_VARIANT: c->opt_variant = (int)value; return RT3_OK;
+        case RT3_OPT_LEAF_SIZE:
+            if (value < 1 || value > 8) return fail(c, RT3_E_INVALID, "leaf size must be 1..8");
+            c->opt_leaf_size = (uint32_t)value;
+            c->accel_built = false;
+            return RT3_OK;
+        case RT3_OPT_NODE_WIDTH:
+            if (value != 2 && value != 4) return fail(c, RT3_E_INVALID, "node width must be 2 or 4");
+            c->opt_node_width = (uint32_t)value;
+            c->accel_built = false;
+            return RT3_OK;
         default: return fail(c, RT3_E_INVALID, "unknown option");
     }
 }
@@ -652,29 +663,34 @@ int rt3_accel_build(rt3_ctx* c, uint32_t* out_handle) {
     dev_free(c->bvh.nodes);
     dev_free(c->bvh.tris);
     dev_free(c->bvh.tri_shade);
-    hipError_t e = lbvh_build(c->stream, c->d_verts, c->d_indices, c->d_geoms, c->d_prim_geom, c->d_first_prim, c->n_prims, &c->bvh);
+    hipError_t e = lbvh_build(c->stream, c->d_verts, c->d_indices, c->d_geoms, c->d_prim_geom, c->d_first_prim, c->n_prims, c->opt_leaf_size,
+                              c->opt_node_width, &c->bvh);
     if (e != hipSuccess) return fail(c, RT3_E_HIP, std::string("lbvh_build: ") + hipGetErrorString(e));
-    if (c->bvh.max_depth > kMaxBvhDepth) {
+    // worst-case stack use of the near-first walk: (children per node - 1) entries per level above the leaves
+    const uint32_t stack_need = c->bvh.max_depth > 1 ? (c->opt_node_width - 1) * (c->bvh.max_depth - 1) : 0;
+    if (stack_need > kMaxStack) {
         dev_free(c->bvh.nodes);
         dev_free(c->bvh.tris);
         dev_free(c->bvh.tri_shade);
-        return fail(c, RT3_E_DEPTH, "LBVH depth " + std::to_string(c->bvh.max_depth) + " exceeds the traversal stack (" + std::to_string(kMaxBvhDepth) + ")");
+        return fail(c, RT3_E_DEPTH, "LBVH with " + std::to_string(c->bvh.max_depth) + " levels needs " + std::to_string(stack_need) +
+                                        " stack entries, the traversal kernels hold " + std::to_string(kMaxStack));
     }
     c->accel_built = true;
     if (out_handle) *out_handle = (RT3_TAG_ACCEL << 30) | 0u;
     return RT3_OK;
 }
-int rt3_accel_info(rt3_ctx* c, uint32_t* n_nodes, uint32_t* n_tris, uint32_t* max_depth) {
+int rt3_accel_info(rt3_ctx* c, uint32_t* n_nodes, uint32_t* n_tris, uint32_t* max_depth, uint32_t* node_bytes) {
     if (!c || !c->accel_built) return fail(c, RT3_E_STATE, "no acceleration structure built");
     if (n_nodes) *n_nodes = c->bvh.n_nodes;
     if (n_tris) *n_tris = c->bvh.n_tris;
     if (max_depth) *max_depth = c->bvh.max_depth;
+    if (node_bytes) *node_bytes = c->bvh.node_bytes;
     return RT3_OK;
 }
 int rt3_accel_download(rt3_ctx* c, void* nodes, size_t nodes_bytes, void* tris, size_t tris_bytes) {
     if (!c || !c->accel_built) return fail(c, RT3_E_STATE, "no acceleration structure built");
     if (nodes) {
-        if (nodes_bytes != (size_t)c->bvh.n_nodes * 64) return fail(c, RT3_E_INVALID, "nodes_bytes mismatch");
+        if (nodes_bytes != (size_t)c->bvh.n_nodes * c->bvh.node_bytes) return fail(c, RT3_E_INVALID, "nodes_bytes mismatch");
         if (nodes_bytes) HIPC(c, hipMemcpy(nodes, c->bvh.nodes, nodes_bytes, hipMemcpyDeviceToHost));
     }
     if (tris) {
@@ -859,9 +875,9 @@ int rt3_trace_rays(rt3_ctx* c, const float* rays, uint32_t n, int any_hit, float
     if (repeat < 1) repeat = 1;
     auto launch = [&]() {
         if (any_hit)
-            launch_shadow(c->stream, count, c->bvh.nodes, c->bvh.tris, d_rays, n, nullptr, n, n, nullptr, nullptr, nullptr, 0, d_occ, d_cn, d_ct, nullptr);
+            launch_shadow(c->stream, count, c->bvh.node_bytes == 128, c->bvh.nodes, c->bvh.tris, d_rays, n, nullptr, n, n, nullptr, nullptr, nullptr, 0, d_occ, d_cn, d_ct, nullptr);
         else
-            launch_extend(c->stream, count, c->bvh.nodes, c->bvh.tris, d_rays, n, nullptr, n, n, d_hits, d_cn, d_ct, nullptr);
+            launch_extend(c->stream, count, c->bvh.node_bytes == 128, c->bvh.nodes, c->bvh.tris, d_rays, n, nullptr, n, n, d_hits, d_cn, d_ct, nullptr);
     };
     launch();  // warm-up (also the result-producing launch)
     TR(hipEventRecord(e0, c->stream));

@@ -21,7 +21,52 @@ constexpr int kLdsStack = 24;
 constexpr int kSpill = 40;  // kLdsStack + kSpill >= kMaxBvhDepth (checked on the host after the build)
 constexpr uint32_t kMaxSteps = 1u << 20;  // safety bound on traversal steps per ray (a corrupt tree must not hang the GPU)
 
-template <bool ANY, bool COUNT>
+constexpr uint32_t kEmptySlot = 0xFFFFFFFFu;
+
+struct Cand {  // a child slot that the ray enters: entry distance + reference, ordered by (tn, slot)
+    float tn;
+    uint32_t ref, slot;
+};
+__device__ __forceinline__ void cswap(Cand& a, Cand& b) {
+    bool sw = b.tn < a.tn || (b.tn == a.tn && b.slot < a.slot);
+    Cand t = a;
+    a.tn = sw ? b.tn : a.tn;
+    a.ref = sw ? b.ref : a.ref;
+    a.slot = sw ? b.slot : a.slot;
+    b.tn = sw ? t.tn : b.tn;
+    b.ref = sw ? t.ref : b.ref;
+    b.slot = sw ? t.slot : b.slot;
+}
+__device__ __forceinline__ void pin(float4& q) { asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w)); }
+// branch-free form of tri_test (same arithmetic, same acceptance rule): no early-outs, so the three loads of a
+// triangle are issued together instead of being sunk behind the det / u / v branches
+__device__ __forceinline__ void tri_test_nb(float4 q0, float4 q1, float4 q2, V3 o, V3 d, float tmin, Hit& best) {
+    V3 v0 = v3(q0.x, q0.y, q0.z), e1 = v3(q0.w, q1.x, q1.y), e2 = v3(q1.z, q1.w, q2.x);
+    V3 pv = cross(d, e2);
+    float det = dot(e1, pv);
+    float inv = 1.0f / det;
+    V3 tv = o - v0;
+    float u = dot(tv, pv) * inv;
+    V3 qv = cross(tv, e1);
+    float v = dot(d, qv) * inv;
+    float t = dot(e2, qv) * inv;
+    uint32_t prim = __float_as_uint(q2.y);
+    bool ok = (det != 0.0f) & (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > tmin) &
+              ((t < best.t) | ((t == best.t) & (prim < best.prim)));
+    best.t = ok ? t : best.t;
+    best.u = ok ? u : best.u;
+    best.v = ok ? v : best.v;
+    best.prim = ok ? prim : best.prim;
+}
+
+// One ray per lane.  WIDE: 128 B nodes with four {min, max, ref, pad} slots; else 64 B binary nodes.
+// Children are visited nearest first (ties: lower slot); the others are pushed so that they pop in ascending entry
+// distance; no re-cull on pop.  A leaf reference holds 1..8 consecutive triangles.
+//
+// The walk is latency-bound (dependent fetches through L2 / Infinity Cache), so every step makes exactly ONE memory
+// round trip: a lane first fetches its next item -- the node, or the next triangle(s) of its current leaf -- with one
+// batch of 16-byte loads issued together, and only then branches into box tests or triangle tests.
+template <bool ANY, bool COUNT, bool WIDE>
 __device__ __forceinline__ Hit traverse(const float4* __restrict__ nodes, const float4* __restrict__ tris, V3 o, V3 d,
                                         float tmin, float tmax, uint32_t* __restrict__ lds, uint32_t& cn, uint32_t& ct) {
     Hit best{tmax, 0.0f, 0.0f, kMiss};
@@ -29,49 +74,110 @@ __device__ __forceinline__ Hit traverse(const float4* __restrict__ nodes, const 
     const V3 inv = v3(guarded_inverse(d.x), guarded_inverse(d.y), guarded_inverse(d.z));
     uint32_t spill[kSpill];
     int sp = 0;
-    uint32_t cur = 0;
+    uint32_t cur = 0, leaf_k = 0;
     // kMaxSteps bounds the walk so that a corrupt tree can never hang the GPU (a valid tree visits < 2 n nodes)
     for (uint32_t step = 0; step < kMaxSteps; ++step) {
-        if (cur & 0x80000000u) {
-            const float4* tp = tris + 3 * (size_t)(cur & 0x7FFFFFFFu);
-            float4 q0 = tp[0], q1 = tp[1], q2 = tp[2];
-            if (COUNT) ct++;
-            tri_test(q0, q1, q2, o, d, tmin, best);
-            if (ANY && best.prim != kMiss) break;
-            if (sp == 0) break;
-            --sp;
-            cur = sp < kLdsStack ? lds[sp * kExtendBlock] : spill[sp - kLdsStack];
-            continue;
+        const bool is_leaf = (cur & 0x80000000u) != 0u;
+        const uint32_t first = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
+        const float4* p = is_leaf ? tris + 3 * (size_t)(first + leaf_k) : nodes + (WIDE ? 8 : 4) * (size_t)cur;
+        // one batch of loads (the triangle array carries 128 B of slack so that over-reading a leaf is in bounds)
+        float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4, q5, q6, q7;
+        if (WIDE) {
+            q4 = p[4];
+            q5 = p[5];
+            q6 = p[6];
+            q7 = p[7];
         }
-        const float4* np = nodes + 4 * (size_t)cur;
-        float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
-        if (COUNT) cn++;
-        float tn0, tn1;
-        bool h0 = slab_test(v3(n0.x, n0.y, n0.z), v3(n0.w, n1.x, n1.y), o, inv, tmin, best.t, tn0);
-        bool h1 = slab_test(v3(n1.z, n1.w, n2.x), v3(n2.y, n2.z, n2.w), o, inv, tmin, best.t, tn1);
-        uint32_t r0 = __float_as_uint(n3.x), r1 = __float_as_uint(n3.y);
-        if (h0 && h1) {
-            bool near1 = tn1 < tn0;
-            uint32_t far = near1 ? r0 : r1;
-            cur = near1 ? r1 : r0;
-            if (sp < kLdsStack) lds[sp * kExtendBlock] = far;
-            else spill[sp - kLdsStack] = far;
-            ++sp;
-        } else if (h0) {
-            cur = r0;
-        } else if (h1) {
-            cur = r1;
+        // pin the fetched registers: without this LLVM sinks the loads only one branch needs into that branch, which
+        // turns one memory round trip per step into two
+        pin(q0); pin(q1); pin(q2); pin(q3);
+        if (WIDE) { pin(q4); pin(q5); pin(q6); pin(q7); }
+        bool pop = false;
+        if (is_leaf) {
+            if (COUNT) ct++;
+            tri_test_nb(q0, q1, q2, o, d, tmin, best);
+            leaf_k++;
+            if (WIDE) {  // the 128 B fetch holds a second triangle
+                if (leaf_k < cnt && !(ANY && best.prim != kMiss)) {
+                    if (COUNT) ct++;
+                    tri_test_nb(q3, q4, q5, o, d, tmin, best);
+                    leaf_k++;
+                }
+            }
+            if (ANY && best.prim != kMiss) break;
+            if (leaf_k >= cnt) {
+                leaf_k = 0;
+                pop = true;
+            }
         } else {
+            if (COUNT) cn++;
+            if (WIDE) {
+                const float kInf = __builtin_huge_valf();
+                float t0, t1, t2, t3;
+                uint32_t r0 = __float_as_uint(q1.z), r1 = __float_as_uint(q3.z), r2 = __float_as_uint(q5.z), r3 = __float_as_uint(q7.z);
+                bool h0 = slab_test(v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), o, inv, tmin, best.t, t0) & (r0 != kEmptySlot);
+                bool h1 = slab_test(v3(q2.x, q2.y, q2.z), v3(q2.w, q3.x, q3.y), o, inv, tmin, best.t, t1) & (r1 != kEmptySlot);
+                bool h2 = slab_test(v3(q4.x, q4.y, q4.z), v3(q4.w, q5.x, q5.y), o, inv, tmin, best.t, t2) & (r2 != kEmptySlot);
+                bool h3 = slab_test(v3(q6.x, q6.y, q6.z), v3(q6.w, q7.x, q7.y), o, inv, tmin, best.t, t3) & (r3 != kEmptySlot);
+                Cand c0{h0 ? t0 : kInf, h0 ? r0 : kEmptySlot, 0u}, c1{h1 ? t1 : kInf, h1 ? r1 : kEmptySlot, 1u};
+                Cand c2{h2 ? t2 : kInf, h2 ? r2 : kEmptySlot, 2u}, c3{h3 ? t3 : kInf, h3 ? r3 : kEmptySlot, 3u};
+                const uint32_t nh = (uint32_t)h0 + (uint32_t)h1 + (uint32_t)h2 + (uint32_t)h3;
+                // 5-comparator sorting network on (tn, slot); non-hits carry tn = +inf and sink to the end
+                cswap(c0, c1);
+                cswap(c2, c3);
+                cswap(c0, c2);
+                cswap(c1, c3);
+                cswap(c1, c2);
+                if (nh > 3) {
+                    if (sp < kLdsStack) lds[sp * kExtendBlock] = c3.ref;
+                    else spill[sp - kLdsStack] = c3.ref;
+                    ++sp;
+                }
+                if (nh > 2) {
+                    if (sp < kLdsStack) lds[sp * kExtendBlock] = c2.ref;
+                    else spill[sp - kLdsStack] = c2.ref;
+                    ++sp;
+                }
+                if (nh > 1) {
+                    if (sp < kLdsStack) lds[sp * kExtendBlock] = c1.ref;
+                    else spill[sp - kLdsStack] = c1.ref;
+                    ++sp;
+                }
+                cur = c0.ref;
+                pop = nh == 0;
+            } else {
+                float tn0, tn1;
+                uint32_t r0 = __float_as_uint(q3.x), r1 = __float_as_uint(q3.y);
+                bool h0 = slab_test(v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), o, inv, tmin, best.t, tn0) & (r0 != kEmptySlot);
+                bool h1 = slab_test(v3(q1.z, q1.w, q2.x), v3(q2.y, q2.z, q2.w), o, inv, tmin, best.t, tn1) & (r1 != kEmptySlot);
+                bool near1 = tn1 < tn0;
+                if (h0 & h1) {
+                    uint32_t far = near1 ? r0 : r1;
+                    if (sp < kLdsStack) lds[sp * kExtendBlock] = far;
+                    else spill[sp - kLdsStack] = far;
+                    ++sp;
+                }
+                cur = (h0 & h1) ? (near1 ? r1 : r0) : (h0 ? r0 : r1);
+                pop = !(h0 | h1);
+            }
+        }
+        if (pop) {
             if (sp == 0) break;
             --sp;
-            cur = sp < kLdsStack ? lds[sp * kExtendBlock] : spill[sp - kLdsStack];
+            // two explicit paths: a pointer select here would turn the pop into a flat_load
+            if (sp < kLdsStack) {
+                cur = lds[sp * kExtendBlock];
+            } else {
+                cur = spill[sp - kLdsStack];
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     return best;
 }
 
 // closest-hit over a ray queue.  rays: 8 SoA streams of `stride` floats; hits: t,u,v,prim streams of `stride`.
-template <bool COUNT>
+template <bool COUNT, bool WIDE>
 __global__ __launch_bounds__(kExtendBlock) void k_extend(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                                          const float* __restrict__ rays, size_t stride,
                                                          const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
@@ -85,7 +191,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(const float4* __restric
         V3 d = v3(rays[3 * stride + i], rays[4 * stride + i], rays[5 * stride + i]);
         float tmin = rays[6 * stride + i], tmax = rays[7 * stride + i];
         uint32_t cn = 0, ct = 0;
-        Hit h = traverse<false, COUNT>(nodes, tris, o, d, tmin, tmax, stack + threadIdx.x, cn, ct);
+        Hit h = traverse<false, COUNT, WIDE>(nodes, tris, o, d, tmin, tmax, stack + threadIdx.x, cn, ct);
         hits[i] = h.t;
         hits[stride + i] = h.u;
         hits[2 * stride + i] = h.v;
@@ -105,7 +211,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(const float4* __restric
 
 // any-hit over the shadow queue; unoccluded rays add their contribution to the path's radiance slot.
 // If `occluded_out` != nullptr the kernel only reports occlusion (rt3_trace_rays).
-template <bool COUNT>
+template <bool COUNT, bool WIDE>
 __global__ __launch_bounds__(kExtendBlock) void k_shadow(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                                          const float* __restrict__ rays, size_t stride,
                                                          const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
@@ -121,7 +227,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_shadow(const float4* __restric
         V3 d = v3(rays[3 * stride + i], rays[4 * stride + i], rays[5 * stride + i]);
         float tmin = rays[6 * stride + i], tmax = rays[7 * stride + i];
         uint32_t cn = 0, ct = 0;
-        Hit h = traverse<true, COUNT>(nodes, tris, o, d, tmin, tmax, stack + threadIdx.x, cn, ct);
+        Hit h = traverse<true, COUNT, WIDE>(nodes, tris, o, d, tmin, tmax, stack + threadIdx.x, cn, ct);
         if (occluded_out) {
             occluded_out[i] = h.prim != kMiss ? 1u : 0u;
         } else if (h.prim == kMiss) {
@@ -590,25 +696,30 @@ static inline unsigned grid_for(uint64_t n, unsigned block, unsigned max_blocks)
 void launch_raygen(hipStream_t st, const GConstDev& g, const uint32_t* pixels, uint32_t npix, float* rays, size_t stride) {
     hipLaunchKernelGGL(k_raygen, dim3(grid_for(npix, 256, 4096)), dim3(256), 0, st, g, pixels, npix, rays, stride);
 }
-void launch_extend(hipStream_t st, bool count, const float4* nodes, const float4* tris, const float* rays, size_t stride,
+void launch_extend(hipStream_t st, bool count, bool wide, const float4* nodes, const float4* tris, const float* rays, size_t stride,
                    const uint32_t* count_ptr, uint32_t count_imm, uint32_t max_n, float* hits, uint32_t* cn, uint32_t* ct,
                    unsigned long long* totals) {
     unsigned grid = grid_for(max_n, kExtendBlock, kExtendMaxBlocks);
-    if (count)
-        hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, hits, cn, ct, totals);
-    else
-        hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, hits, cn, ct, totals);
+#define RT3_LAUNCH_EXTEND(C, W) \
+    hipLaunchKernelGGL((k_extend<C, W>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, hits, cn, ct, totals)
+    if (count && wide) RT3_LAUNCH_EXTEND(true, true);
+    else if (count) RT3_LAUNCH_EXTEND(true, false);
+    else if (wide) RT3_LAUNCH_EXTEND(false, true);
+    else RT3_LAUNCH_EXTEND(false, false);
+#undef RT3_LAUNCH_EXTEND
 }
-void launch_shadow(hipStream_t st, bool count, const float4* nodes, const float4* tris, const float* rays, size_t stride,
+void launch_shadow(hipStream_t st, bool count, bool wide, const float4* nodes, const float4* tris, const float* rays, size_t stride,
                    const uint32_t* count_ptr, uint32_t count_imm, uint32_t max_n, const float* contrib, const uint32_t* pid, float* lacc,
                    size_t lstride, uint32_t* occluded_out, uint32_t* cn, uint32_t* ct, unsigned long long* totals) {
     unsigned grid = grid_for(max_n, kExtendBlock, kExtendMaxBlocks);
-    if (count)
-        hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, contrib, pid,
-                           lacc, lstride, occluded_out, cn, ct, totals);
-    else
-        hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, contrib, pid,
-                           lacc, lstride, occluded_out, cn, ct, totals);
+#define RT3_LAUNCH_SHADOW(C, W)                                                                                                                \
+    hipLaunchKernelGGL((k_shadow<C, W>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, contrib, pid, lacc, \
+                       lstride, occluded_out, cn, ct, totals)
+    if (count && wide) RT3_LAUNCH_SHADOW(true, true);
+    else if (count) RT3_LAUNCH_SHADOW(true, false);
+    else if (wide) RT3_LAUNCH_SHADOW(false, true);
+    else RT3_LAUNCH_SHADOW(false, false);
+#undef RT3_LAUNCH_SHADOW
 }
 void launch_gbuffer(hipStream_t st, const SceneDev& sc, const uint32_t* pixels, uint32_t npix, uint32_t width, const float* hits,
                     size_t stride, void* gbuffer, float* depth) {

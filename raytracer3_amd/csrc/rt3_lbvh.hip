@@ -6,9 +6,12 @@
 //   hipcub radix sort of (code, primitive) pairs, 64-bit keys, stable -> ties keep primitive order
 //   k_leaves       Morton-ordered triangle records {v0,e1,e2,prim} (48 B) + padded leaf boxes
 //   k_hierarchy    Karras 2012 radix-tree topology, one thread per internal node
-//   k_refit        bottom-up boxes: the second thread to arrive at a node (agent-scope atomic + fences) fills the
-//                  64 B traversal node {child0 box, child1 box, child refs} and climbs on
-//   k_depth        tree depth (host checks it against the traversal stack)
+//   k_refit        bottom-up boxes of every binary node: the second thread to arrive at a node (agent-scope atomic +
+//                  fences) merges the two child boxes and climbs on
+//   k_keep_flags   binary depth of every node (parent walk); multi-triangle leaves: a node covering <= leaf_max
+//                  triangles is referenced as a leaf; wide nodes: even-depth nodes survive and absorb their children
+//   hipcub exclusive scan of the keep flags -> dense node numbering in index order
+//   k_emit_nodes   64 B binary nodes {box0, box1, ref0, ref1} or 128 B four-wide nodes 4 x {min, max, ref, pad}
 // min/max are exact, so the tree is a pure function of the input and is compared bit for bit with the CPU oracle.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -157,7 +160,8 @@ __device__ __forceinline__ int delta(const uint64_t* codes, int n, int i, int j)
 }
 
 // Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees", HPG 2012, section 4
-__global__ void k_hierarchy(const uint64_t* codes, int n, uint32_t* left, uint32_t* right, uint32_t* parent_internal, uint32_t* parent_leaf) {
+__global__ void k_hierarchy(const uint64_t* codes, int n, uint32_t* left, uint32_t* right, uint32_t* parent_internal, uint32_t* parent_leaf,
+                            uint32_t* range_lo, uint32_t* range_cnt) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n - 1; i += gridDim.x * blockDim.x) {
         int d = (delta(codes, n, i, i + 1) - delta(codes, n, i, i - 1)) >= 0 ? 1 : -1;
         int dmin = delta(codes, n, i, i - d);
@@ -175,6 +179,8 @@ __global__ void k_hierarchy(const uint64_t* codes, int n, uint32_t* left, uint32
         } while (t > 1);
         int gamma = i + s * d + (d < 0 ? d : 0);
         int lo = i < j ? i : j, hi = i < j ? j : i;
+        range_lo[i] = (uint32_t)lo;
+        range_cnt[i] = (uint32_t)(hi - lo + 1);
         if (lo == gamma) {
             left[i] = 0x80000000u | (uint32_t)gamma;
             parent_leaf[gamma] = (uint32_t)i;
@@ -193,11 +199,11 @@ __global__ void k_hierarchy(const uint64_t* codes, int n, uint32_t* left, uint32
     }
 }
 
-// bottom-up refit.  nbox holds each internal node's own box (6 floats).  Inter-workgroup hand-off of a child's box goes
+// bottom-up refit.  nbox holds each binary node's own box (6 floats).  Inter-workgroup hand-off of a child's box goes
 // through an agent-scope fence + returning atomic on the node's arrival counter, then an agent-scope fence on the
 // consumer before it reads (per-XCD L2s are not coherent).
 __global__ void k_refit(const uint32_t* left, const uint32_t* right, const uint32_t* parent_internal, const uint32_t* parent_leaf,
-                        const float* lmin, const float* lmax, uint32_t n, float* nbox, uint32_t* arrive, float4* nodes) {
+                        const float* lmin, const float* lmax, uint32_t n, float* nbox, uint32_t* arrive) {
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
         uint32_t cur = parent_leaf[k];
         while (cur != 0xFFFFFFFFu) {
@@ -224,10 +230,6 @@ __global__ void k_refit(const uint32_t* left, const uint32_t* right, const uint3
                     }
                 }
             }
-            nodes[4 * (size_t)cur + 0] = make_float4(mn[0][0], mn[0][1], mn[0][2], mx[0][0]);
-            nodes[4 * (size_t)cur + 1] = make_float4(mx[0][1], mx[0][2], mn[1][0], mn[1][1]);
-            nodes[4 * (size_t)cur + 2] = make_float4(mn[1][2], mx[1][0], mx[1][1], mx[1][2]);
-            nodes[4 * (size_t)cur + 3] = make_float4(__uint_as_float(ch[0]), __uint_as_float(ch[1]), 0.0f, 0.0f);
 #pragma unroll
             for (int j = 0; j < 3; j++) {
                 __hip_atomic_store(&nbox[6 * (size_t)cur + j], fmin_sel(mn[0][j], mn[1][j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -238,25 +240,119 @@ __global__ void k_refit(const uint32_t* left, const uint32_t* right, const uint3
     }
 }
 
-__global__ void k_depth(const uint32_t* parent_internal, const uint32_t* parent_leaf, uint32_t n, uint32_t* max_depth) {
+// binary depth (root = 0) by walking the parents; keep[i] = 1 if node i survives into the traversal array:
+// it covers more than leaf_max triangles (or is the root) and, for four-wide nodes, sits at an even depth.
+__global__ void k_keep_flags(const uint32_t* parent_internal, const uint32_t* range_cnt, uint32_t nn, uint32_t leaf_max, int wide,
+                             uint32_t* keep, uint32_t* max_levels) {
     uint32_t best = 0;
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n; k += gridDim.x * blockDim.x) {
-        uint32_t d = 1, cur = parent_leaf[k];
-        while (cur != 0xFFFFFFFFu) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += gridDim.x * blockDim.x) {
+        uint32_t d = 0, p = parent_internal[i];
+        while (p != 0xFFFFFFFFu) {
             d++;
-            cur = parent_internal[cur];
+            p = parent_internal[p];
         }
-        best = d > best ? d : best;
+        bool live = i == 0 || range_cnt[i] > leaf_max;
+        bool k = live && (!wide || (d & 1u) == 0u);
+        keep[i] = k ? 1u : 0u;
+        if (k) {
+            uint32_t lvl = (wide ? d / 2u : d) + 2u;  // levels from the root down to this node's leaf slots
+            best = lvl > best ? lvl : best;
+        }
     }
-    if (best) atomicMax(max_depth, best);
+    if (best) atomicMax(max_levels, best);
 }
 
-// single-triangle scene: root with child0 = the leaf and an empty child1 box
-__global__ void k_single(const float* lmin, const float* lmax, float4* nodes) {
-    nodes[0] = make_float4(lmin[0], lmin[1], lmin[2], lmax[0]);
-    nodes[1] = make_float4(lmax[1], lmax[2], INFINITY, INFINITY);
-    nodes[2] = make_float4(INFINITY, -INFINITY, -INFINITY, -INFINITY);
-    nodes[3] = make_float4(__uint_as_float(0x80000000u), __uint_as_float(0x80000000u), 0.0f, 0.0f);
+__device__ __forceinline__ void slot_of(uint32_t ch, const float* lmin, const float* lmax, const float* nbox, const uint32_t* range_lo,
+                                        const uint32_t* range_cnt, const uint32_t* newidx, uint32_t leaf_max, float mn[3], float mx[3], uint32_t& ref) {
+    if (ch & 0x80000000u) {
+        uint32_t q = ch & 0x7FFFFFFFu;
+        ref = 0x80000000u | q;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            mn[j] = lmin[3 * (size_t)q + j];
+            mx[j] = lmax[3 * (size_t)q + j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            mn[j] = nbox[6 * (size_t)ch + j];
+            mx[j] = nbox[6 * (size_t)ch + 3 + j];
+        }
+        bool live = range_cnt[ch] > leaf_max;  // ch != 0: the root is nobody's child
+        ref = live ? newidx[ch] : (0x80000000u | ((range_cnt[ch] - 1u) << 28) | range_lo[ch]);
+    }
+}
+
+// one thread per surviving node: gather its 2 (binary) or 2..4 (wide: internal children are absorbed) child slots
+__global__ void k_emit_nodes(const uint32_t* left, const uint32_t* right, const uint32_t* range_lo, const uint32_t* range_cnt,
+                             const uint32_t* keep, const uint32_t* newidx, const float* lmin, const float* lmax, const float* nbox,
+                             uint32_t nn, uint32_t leaf_max, int wide, float4* nodes) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += gridDim.x * blockDim.x) {
+        if (!keep[i]) continue;
+        uint32_t s0 = left[i], s1 = right[i], s2 = 0xFFFFFFFFu, s3 = 0xFFFFFFFFu;
+        bool v2 = false, v3 = false;
+        if (wide) {  // absorb internal children that are not collapsed into leaves: their two children become slots
+            bool e0 = !(s0 & 0x80000000u) && range_cnt[s0] > leaf_max, e1 = !(s1 & 0x80000000u) && range_cnt[s1] > leaf_max;
+            uint32_t a0 = s0, a1 = s1;
+            if (e0 && e1) {
+                s0 = left[a0]; s1 = right[a0]; s2 = left[a1]; s3 = right[a1];
+                v2 = v3 = true;
+            } else if (e0) {
+                s0 = left[a0]; s1 = right[a0]; s2 = a1;
+                v2 = true;
+            } else if (e1) {
+                s1 = left[a1]; s2 = right[a1];
+                v2 = true;
+            }
+        }
+        const uint32_t o = newidx[i];
+        float mn[3], mx[3];
+        uint32_t ref;
+        if (wide) {
+            const float inf = INFINITY;
+            const uint32_t sl[4] = {s0, s1, s2, s3};
+            const bool vl[4] = {true, true, v2, v3};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (vl[k]) {
+                    slot_of(sl[k], lmin, lmax, nbox, range_lo, range_cnt, newidx, leaf_max, mn, mx, ref);
+                } else {
+                    mn[0] = mn[1] = mn[2] = inf;
+                    mx[0] = mx[1] = mx[2] = -inf;
+                    ref = 0xFFFFFFFFu;
+                }
+                nodes[8 * (size_t)o + 2 * k] = make_float4(mn[0], mn[1], mn[2], mx[0]);
+                nodes[8 * (size_t)o + 2 * k + 1] = make_float4(mx[1], mx[2], __uint_as_float(ref), 0.0f);
+            }
+        } else {
+            float mn1[3], mx1[3];
+            uint32_t ref1;
+            slot_of(s0, lmin, lmax, nbox, range_lo, range_cnt, newidx, leaf_max, mn, mx, ref);
+            slot_of(s1, lmin, lmax, nbox, range_lo, range_cnt, newidx, leaf_max, mn1, mx1, ref1);
+            nodes[4 * (size_t)o + 0] = make_float4(mn[0], mn[1], mn[2], mx[0]);
+            nodes[4 * (size_t)o + 1] = make_float4(mx[1], mx[2], mn1[0], mn1[1]);
+            nodes[4 * (size_t)o + 2] = make_float4(mn1[2], mx1[0], mx1[1], mx1[2]);
+            nodes[4 * (size_t)o + 3] = make_float4(__uint_as_float(ref), __uint_as_float(ref1), 0.0f, 0.0f);
+        }
+    }
+}
+
+// single-triangle scene: root with the leaf in slot 0 and empty other slots
+__global__ void k_single(const float* lmin, const float* lmax, int wide, float4* nodes) {
+    const float inf = INFINITY;
+    if (wide) {
+        nodes[0] = make_float4(lmin[0], lmin[1], lmin[2], lmax[0]);
+        nodes[1] = make_float4(lmax[1], lmax[2], __uint_as_float(0x80000000u), 0.0f);
+        for (int k = 1; k < 4; k++) {
+            nodes[2 * k] = make_float4(inf, inf, inf, -inf);
+            nodes[2 * k + 1] = make_float4(-inf, -inf, __uint_as_float(0xFFFFFFFFu), 0.0f);
+        }
+    } else {
+        nodes[0] = make_float4(lmin[0], lmin[1], lmin[2], lmax[0]);
+        nodes[1] = make_float4(lmax[1], lmax[2], inf, inf);
+        nodes[2] = make_float4(inf, -inf, -inf, -inf);
+        nodes[3] = make_float4(__uint_as_float(0x80000000u), __uint_as_float(0xFFFFFFFFu), 0.0f, 0.0f);
+    }
 }
 
 #define LB_CHECK(x)                  \
@@ -269,20 +365,23 @@ __global__ void k_single(const float* lmin, const float* lmax, float4* nodes) {
     } while (0)
 
 hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,
-                      const uint32_t* first_prim, uint32_t n, LbvhResult* out) {
+                      const uint32_t* first_prim, uint32_t n, uint32_t leaf_max, uint32_t node_width, LbvhResult* out) {
     hipError_t err = hipSuccess;
     *out = LbvhResult{};
     out->n_tris = n;
+    const int wide = node_width == 4;
+    out->node_bytes = wide ? 128u : 64u;
     if (n == 0) return hipSuccess;
     const uint32_t nn = n > 1 ? n - 1 : 1;
     float *bmin = nullptr, *bmax = nullptr, *lmin = nullptr, *lmax = nullptr, *nbox = nullptr;
     uint32_t *bounds = nullptr, *vals_in = nullptr, *vals_out = nullptr, *left = nullptr, *right = nullptr, *pint = nullptr, *pleaf = nullptr,
-             *arrive = nullptr, *depth = nullptr;
+             *arrive = nullptr, *levels = nullptr, *rlo = nullptr, *rcnt = nullptr, *keep = nullptr, *newidx = nullptr;
     uint64_t *keys_in = nullptr, *keys_out = nullptr;
-    void* temp = nullptr;
-    size_t temp_bytes = 0;
+    void *temp = nullptr, *temp2 = nullptr;
+    size_t temp_bytes = 0, temp2_bytes = 0;
     const unsigned grid = (unsigned)(((uint64_t)n + 255) / 256 > 4096 ? 4096 : ((uint64_t)n + 255) / 256);
     uint32_t init_bounds[12];
+    uint32_t tail[2] = {0, 0};
     for (int k = 0; k < 3; k++) {
         init_bounds[k] = 0xFFFFFFFFu;
         init_bounds[3 + k] = 0u;
@@ -304,15 +403,17 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
     LB_CHECK(hipMalloc(&pint, (size_t)nn * 4));
     LB_CHECK(hipMalloc(&pleaf, (size_t)n * 4));
     LB_CHECK(hipMalloc(&arrive, (size_t)nn * 4));
-    LB_CHECK(hipMalloc(&depth, 4));
-    LB_CHECK(hipMalloc(&out->nodes, (size_t)nn * 64));
-    LB_CHECK(hipMalloc(&out->tris, (size_t)n * 48));
+    LB_CHECK(hipMalloc(&rlo, (size_t)nn * 4));
+    LB_CHECK(hipMalloc(&rcnt, (size_t)nn * 4));
+    LB_CHECK(hipMalloc(&keep, (size_t)nn * 4));
+    LB_CHECK(hipMalloc(&newidx, (size_t)nn * 4));
+    LB_CHECK(hipMalloc(&levels, 4));
+    LB_CHECK(hipMalloc(&out->tris, (size_t)n * 48 + 128));  // + slack: the traversal fetch may over-read the last leaf by up to 128 B
+    LB_CHECK(hipMemsetAsync((char*)out->tris + (size_t)n * 48, 0, 128, st));
     LB_CHECK(hipMalloc(&out->tri_shade, (size_t)n * 64));
-    out->n_nodes = nn;
     LB_CHECK(hipMemcpyAsync(bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, st));
     LB_CHECK(hipMemsetAsync(arrive, 0, (size_t)nn * 4, st));
-    LB_CHECK(hipMemsetAsync(depth, 0, 4, st));
-    LB_CHECK(hipMemsetAsync(out->nodes, 0, (size_t)nn * 64, st));
+    LB_CHECK(hipMemsetAsync(levels, 0, 4, st));
     hipLaunchKernelGGL(k_prim_bounds, dim3(grid), dim3(256), 0, st, verts, indices, geoms, prim_geom, first_prim, n, bmin, bmax, bounds);
     hipLaunchKernelGGL(k_tri_shade, dim3(grid), dim3(256), 0, st, verts, indices, geoms, prim_geom, first_prim, n, out->tri_shade);
     hipLaunchKernelGGL(k_morton, dim3(grid), dim3(256), 0, st, bmin, bmax, bounds, n, keys_in, vals_in);
@@ -322,19 +423,34 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
     hipLaunchKernelGGL(k_leaves, dim3(grid), dim3(256), 0, st, verts, indices, geoms, prim_geom, first_prim, vals_out, bmin, bmax, bounds, n,
                        out->tris, lmin, lmax);
     if (n == 1) {
-        hipLaunchKernelGGL(k_single, dim3(1), dim3(1), 0, st, lmin, lmax, out->nodes);
-        out->max_depth = 1;
+        LB_CHECK(hipMalloc(&out->nodes, out->node_bytes));
+        hipLaunchKernelGGL(k_single, dim3(1), dim3(1), 0, st, lmin, lmax, wide, out->nodes);
+        out->n_nodes = 1;
+        out->max_depth = 2;
+        LB_CHECK(hipGetLastError());
+        LB_CHECK(hipStreamSynchronize(st));
     } else {
-        hipLaunchKernelGGL(k_hierarchy, dim3(grid), dim3(256), 0, st, keys_out, (int)n, left, right, pint, pleaf);
-        hipLaunchKernelGGL(k_refit, dim3(grid), dim3(256), 0, st, left, right, pint, pleaf, lmin, lmax, n, nbox, arrive, out->nodes);
-        hipLaunchKernelGGL(k_depth, dim3(grid), dim3(256), 0, st, pint, pleaf, n, depth);
-        LB_CHECK(hipMemcpyAsync(&out->max_depth, depth, 4, hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(k_hierarchy, dim3(grid), dim3(256), 0, st, keys_out, (int)n, left, right, pint, pleaf, rlo, rcnt);
+        hipLaunchKernelGGL(k_refit, dim3(grid), dim3(256), 0, st, left, right, pint, pleaf, lmin, lmax, n, nbox, arrive);
+        hipLaunchKernelGGL(k_keep_flags, dim3(grid), dim3(256), 0, st, pint, rcnt, nn, leaf_max, wide, keep, levels);
+        LB_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, temp2_bytes, keep, newidx, (int)nn, st));
+        LB_CHECK(hipMalloc(&temp2, temp2_bytes ? temp2_bytes : 16));
+        LB_CHECK(hipcub::DeviceScan::ExclusiveSum(temp2, temp2_bytes, keep, newidx, (int)nn, st));
+        LB_CHECK(hipMemcpyAsync(&tail[0], newidx + (nn - 1), 4, hipMemcpyDeviceToHost, st));
+        LB_CHECK(hipMemcpyAsync(&tail[1], keep + (nn - 1), 4, hipMemcpyDeviceToHost, st));
+        LB_CHECK(hipMemcpyAsync(&out->max_depth, levels, 4, hipMemcpyDeviceToHost, st));
+        LB_CHECK(hipStreamSynchronize(st));
+        out->n_nodes = tail[0] + tail[1];
+        LB_CHECK(hipMalloc(&out->nodes, (size_t)out->n_nodes * out->node_bytes));
+        hipLaunchKernelGGL(k_emit_nodes, dim3(grid), dim3(256), 0, st, left, right, rlo, rcnt, keep, newidx, lmin, lmax, nbox, nn, leaf_max, wide,
+                           out->nodes);
+        LB_CHECK(hipGetLastError());
+        LB_CHECK(hipStreamSynchronize(st));
     }
-    LB_CHECK(hipGetLastError());
-    LB_CHECK(hipStreamSynchronize(st));
 done:
     for (void* p : {(void*)bmin, (void*)bmax, (void*)lmin, (void*)lmax, (void*)nbox, (void*)bounds, (void*)keys_in, (void*)keys_out, (void*)vals_in,
-                    (void*)vals_out, (void*)left, (void*)right, (void*)pint, (void*)pleaf, (void*)arrive, (void*)depth, temp})
+                    (void*)vals_out, (void*)left, (void*)right, (void*)pint, (void*)pleaf, (void*)arrive, (void*)levels, (void*)rlo, (void*)rcnt,
+                    (void*)keep, (void*)newidx, temp, temp2})
         (void)hipFree(p);
     if (err != hipSuccess) {
         (void)hipFree(out->nodes);

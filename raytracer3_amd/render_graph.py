@@ -185,13 +185,14 @@ class Context:
         return out.value
 
     def accel_info(self):
-        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
-        self.check(self.lib.rt3_accel_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
-        return a.value, b.value, c.value
+        """(n_nodes, n_tris, levels, node_bytes)"""
+        a, b, c, d = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self.check(self.lib.rt3_accel_info(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return a.value, b.value, c.value, d.value
 
     def accel_download(self):
-        nn, nt, _ = self.accel_info()
-        nodes = np.empty((nn, 16), np.uint32)
+        nn, nt, _, nb = self.accel_info()
+        nodes = np.empty((nn, nb // 4), np.uint32)
         tris = np.empty((nt, 12), np.uint32)
         self.check(self.lib.rt3_accel_download(self.h, nodes.ctypes.data, nodes.nbytes, tris.ctypes.data, tris.nbytes))
         return nodes, tris

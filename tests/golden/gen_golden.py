@@ -44,7 +44,7 @@ def scene_fixture(name, mesh, sky, bn, cam, W, H, spp, bounces, flags, frame):
     np.savez_compressed(OUT / f"{name}.npz", vertices=mesh.vertices, indices=mesh.indices, geometries=mesh.geometries, prim_counts=mesh.prim_counts,
                         sky=(sky if sky is not None else np.zeros((0, 0, 3), np.float32)), gconst=gbytes(g), gbuffer=gb, depth=depth, light=light,
                         counts=counts, rays=rays, hit_t=t, hit_u=u, hit_v=v, hit_prim=p, n_nodes=nn, n_tris=nt, occluded=occ,
-                        bvh_nodes=osc.nodes()[:, :14], bvh_tris=osc.tris())
+                        bvh_nodes=osc.nodes(), bvh_tris=osc.tris())
     print(name, mesh.n_triangles, "tris", W, H, "mean", float(light[..., :3].mean()), "file KB", (OUT / f"{name}.npz").stat().st_size // 1024)
 
 

@@ -54,17 +54,29 @@ def test_device_is_gfx950():
     ctx.close()
 
 
-def test_lbvh_bit_identical_to_oracle(small):
-    mesh, sky, bn, osc = small
+@pytest.mark.parametrize("leaf,width", [(2, 4), (1, 2), (4, 4), (8, 4), (4, 2)])
+def test_lbvh_bit_identical_to_oracle(small, leaf, width):
+    """every layout: 64 B binary / 128 B four-wide nodes x 1..8 triangles per leaf"""
+    mesh, sky, bn, _ = small
+    osc = orc.Scene(mesh, leaf_size=leaf, node_width=width)
     ctx = Context(0)
+    ctx.set_option(L.OPT_LEAF_SIZE, leaf)
+    ctx.set_option(L.OPT_NODE_WIDTH, width)
     ctx.upload_mesh(mesh)
     handle = ctx.build_accel()
     assert handle >> 30 == L.TAG_ACCEL
-    nn, nt, depth = ctx.accel_info()
-    assert (nn, nt, depth) == (osc.n_nodes, osc.n_tris, osc.max_depth)
+    nn, nt, levels, nb = ctx.accel_info()
+    assert (nn, nt, levels, nb) == (osc.n_nodes, osc.n_tris, osc.max_depth, 64 if width == 2 else 128)
     nodes, tris = ctx.accel_download()
     assert np.array_equal(tris, osc.tris())
-    assert np.array_equal(nodes[:, :14], osc.nodes()[:, :14])
+    assert np.array_equal(nodes, osc.nodes())
+    # traversal (hits AND per-ray node / triangle counts) agrees in this layout too
+    rays = rays_random(20000, 5, [-14, 0.2, -8], [14, 12, 8])
+    t, u, v, p, cn, ct, _ = ctx.trace_rays(rays, counts=True)
+    ot, ou, ov, op, ocn, oct = osc.trace_closest(rays, counts=True)
+    assert np.array_equal(p, op) and np.array_equal(t[p != L.MISS], ot[p != L.MISS]) and np.array_equal(cn, ocn) and np.array_equal(ct, oct)
+    occ, _, _, o_occ = None, None, None, osc.trace_any(rays)
+    assert np.array_equal(ctx.trace_rays(rays, any_hit=True)[3] != 0, o_occ != 0)
     ctx.close()
 
 
@@ -92,7 +104,7 @@ def test_lbvh_edge_cases():
     ctx.build_accel()
     od = orc.Scene(dup)
     nodes, tris = ctx.accel_download()
-    assert np.array_equal(tris, od.tris()) and np.array_equal(nodes[:, :14], od.nodes()[:, :14])
+    assert np.array_equal(tris, od.tris()) and np.array_equal(nodes, od.nodes())
     t, u, v, p, _ = ctx.trace_rays(rays)
     assert p[0] == 0 and p[1] == L.MISS
     # empty scene: everything misses, passes are no-ops

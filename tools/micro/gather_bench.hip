@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void k(const float4* __restrict__ nodes, uint3
             uint32_t mine = __float_as_uint(a.x);
             nxt = __shfl(mine, (threadIdx.x & 63 & ~3u) + 3);
         }
-        cur = (nxt ^ (s * 40503u)) & mask;
+        cur = ((nxt ^ (s * 40503u)) + tid * 2246822519u) * 2654435761u >> 7 & mask;  // per-thread stream: walks must not coalesce
     }
     if (acc == 123.456f) out[0] = 1;
     out[1 + (tid & 1023)] = cur;
