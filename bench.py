@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--batch-spp", type=int, default=0)
     ap.add_argument("--leaf-size", type=int, default=0, help="triangles per BVH leaf (0 = library default)")
     ap.add_argument("--node-width", type=int, default=0, help="2 | 4 (0 = library default)")
+    ap.add_argument("--node-quant", type=int, default=-1, help="0 | 1 (-1 = library default)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-crop", type=str, default="960x540")
     args = ap.parse_args()
@@ -76,6 +77,8 @@ def main():
         pt.ctx.set_option(L.OPT_LEAF_SIZE, args.leaf_size)
     if args.node_width:
         pt.ctx.set_option(L.OPT_NODE_WIDTH, args.node_width)
+    if args.node_quant >= 0:
+        pt.ctx.set_option(L.OPT_NODE_QUANT, args.node_quant)
     pt.set_scene(mesh, sky, bn)
     if args.batch_spp:
         pt.ctx.set_option(L.OPT_BATCH_SPP, args.batch_spp)
@@ -163,7 +166,7 @@ def main():
         x0, y0 = (W - cw) // 2, (H - ch) // 2
         rect = (x0, y0, x0 + cw, y0 + ch)
         threads = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 256)
-        osc = orc.Scene(mesh, sky, bn, leaf_size=args.leaf_size or 2, node_width=args.node_width or 4)
+        osc = orc.Scene(mesh, sky, bn, leaf_size=args.leaf_size or 2, node_width=args.node_width or 4, quantized=(1 if args.node_quant < 0 else args.node_quant))
         og = orc.GConst()
         C.memmove(C.byref(og), C.byref(g_last), 304)
         ogb, odepth = osc.gbuffer(og, rect=rect, threads=threads)

@@ -403,7 +403,7 @@ struct orc_scene {
     orc_geometry_info *geoms; uint32_t *prim_counts, *first_prim; uint32_t n_geoms;
     uint32_t n_prims; uint32_t *prim_geom;
     /* accel */
-    uint32_t n_tris, n_nodes, max_depth, leaf_max, node_width;
+    uint32_t n_tris, n_nodes, max_depth, leaf_max, node_width, node_quant;
     float *nodes;   /* 16 words per node */
     float *tris;    /* 12 words per tri (Morton order) */
     uint64_t *codes;
@@ -418,14 +418,69 @@ orc_scene *orc_scene_create(void) {
     orc_scene *s = (orc_scene *)calloc(1, sizeof(orc_scene));
     s->leaf_max = 2;
     s->node_width = 4;
+    s->node_quant = 1;
     return s;
 }
 /* leaf_max: 1..8 triangles per leaf; node_width: 2 (64 B nodes) or 4 (128 B nodes).  Call before orc_accel_build. */
-void orc_accel_set_layout(orc_scene *s, uint32_t leaf_max, uint32_t node_width) {
+void orc_accel_set_layout(orc_scene *s, uint32_t leaf_max, uint32_t node_width, uint32_t quantized) {
     s->leaf_max = leaf_max < 1 ? 1 : (leaf_max > 8 ? 8 : leaf_max);
     s->node_width = node_width == 2 ? 2 : 4;
+    s->node_quant = (quantized && s->node_width == 4) ? 1 : 0;
 }
-uint32_t orc_accel_node_words(const orc_scene *s) { return s->node_width == 2 ? 16u : 32u; }
+uint32_t orc_accel_node_words(const orc_scene *s) { return (s->node_width == 2 || s->node_quant) ? 16u : 32u; }
+
+/* [north_star] 64-byte four-wide node with quantised child boxes:
+ *   words 0-2  origin = min corner of the union of the child boxes
+ *   word  3    biased exponents ex | ey << 8 | ez << 16 of the per-axis power-of-two grid step (scale = 2^(e-127))
+ *   words 4-9  24 bytes: child k at bytes 6k..6k+5 = qlo.xyz, qhi.xyz (8 bit each)
+ *   words 10-13 the four child references, words 14-15 zero
+ * decode: lo = origin + float(qlo) * scale, hi = origin + float(qhi) * scale.  Quantisation is conservative with
+ * respect to exactly that decode expression (lo' <= lo, hi' >= hi), so no hit can be lost; empty slots keep ref
+ * 0xFFFFFFFF and are skipped by reference. */
+static void quantize_node(const float mn[4][3], const float mx[4][3], const uint32_t ref[4], uint32_t ns, uint32_t out[16]) {
+    float org[3]; uint32_t eb[3]; uint8_t q[4][6];
+    memset(q, 0, sizeof(q));
+    for (int a = 0; a < 3; a++) {
+        float lo = mn[0][a], hi = mx[0][a];
+        for (uint32_t k = 1; k < ns; k++) { lo = fminx(lo, mn[k][a]); hi = fmaxx(hi, mx[k][a]); }
+        org[a] = lo;
+        float sdiv = (hi - lo) / 255.0f;
+        uint32_t bits = f2u(sdiv), e = (bits >> 23) & 0xFFu;
+        if (bits & 0x7FFFFFu) e += 1;
+        if (e < 1) e = 1;
+        for (;;) { /* grow the step until every child fits in 8 bits */
+            float scale = u2f(e << 23);
+            uint32_t worst = 0;
+            for (uint32_t k = 0; k < ns; k++) {
+                float fl = floorf((mn[k][a] - lo) / scale);
+                uint32_t ql = fl > 255.0f ? 255u : (uint32_t)fl;
+                while (ql > 0 && lo + (float)ql * scale > mn[k][a]) ql--;
+                float fh = ceilf((mx[k][a] - lo) / scale);
+                uint32_t qh = fh > 1024.0f ? 1024u : (uint32_t)fh;
+                while (qh < 1024u && lo + (float)qh * scale < mx[k][a]) qh++;
+                if (qh > worst) worst = qh;
+                q[k][a] = (uint8_t)ql; q[k][3 + a] = (uint8_t)(qh > 255u ? 255u : qh);
+            }
+            if (worst <= 255u) break;
+            e++;
+        }
+        eb[a] = e;
+    }
+    memset(out, 0, 64);
+    out[0] = f2u(org[0]); out[1] = f2u(org[1]); out[2] = f2u(org[2]);
+    out[3] = eb[0] | (eb[1] << 8) | (eb[2] << 16);
+    uint8_t *bytes = (uint8_t *)(out + 4);
+    for (uint32_t k = 0; k < 4; k++) for (int j = 0; j < 6; j++) bytes[6 * k + j] = k < ns ? q[k][j] : (j < 3 ? 255 : 0);
+    for (uint32_t k = 0; k < 4; k++) out[10 + k] = k < ns ? ref[k] : 0xFFFFFFFFu;
+}
+static void dequantize_slot(const uint32_t *nd, int k, float box[6]) {
+    const uint8_t *bytes = (const uint8_t *)(nd + 4);
+    for (int a = 0; a < 3; a++) {
+        float scale = u2f(((nd[3] >> (8 * a)) & 0xFFu) << 23), org = u2f(nd[a]);
+        box[a] = org + (float)bytes[6 * k + a] * scale;
+        box[3 + a] = org + (float)bytes[6 * k + 3 + a] * scale;
+    }
+}
 static void accel_free(orc_scene *s) {
     free(s->nodes); free(s->tris); free(s->codes);
     s->nodes = s->tris = NULL; s->codes = NULL; s->n_tris = s->n_nodes = 0;
@@ -602,9 +657,14 @@ int orc_accel_build(orc_scene *s) {
     uint32_t nn = n > 1 ? n - 1 : 1;
     s->n_nodes = nn;
     if (n == 1) { /* root with the single leaf in slot 0, the other slots empty */
-        const uint32_t W4 = s->node_width == 4, words = W4 ? 32u : 16u;
+        const uint32_t W4 = s->node_width == 4, words = (W4 && !s->node_quant) ? 32u : 16u;
         s->nodes = (float *)calloc(words, 4);
         float *nd = s->nodes;
+        if (s->node_quant) {
+            float qmn[4][3], qmx[4][3]; uint32_t qref[4] = {0x80000000u, 0, 0, 0};
+            memcpy(qmn[0], lmin, 12); memcpy(qmx[0], lmax, 12);
+            quantize_node(qmn, qmx, qref, 1, (uint32_t *)nd);
+        } else
         for (uint32_t k = 0; k < (W4 ? 4u : 2u); k++) {
             float *mn = W4 ? nd + 8 * k : nd + 6 * k, *mx = mn + 3;
             for (int j = 0; j < 3; j++) { mn[j] = k ? INFINITY : lmin[j]; mx[j] = k ? -INFINITY : lmax[j]; }
@@ -668,7 +728,8 @@ int orc_accel_build(orc_scene *s) {
 #define ORC_KEEP(i) (ORC_LIVE(i) && (!W4 || (depth[i] & 1u) == 0))
         uint32_t *newidx = (uint32_t *)malloc((size_t)nn * 4), kept = 0, maxd = 0;
         for (uint32_t i = 0; i < nn; i++) { newidx[i] = kept; if (ORC_KEEP(i)) kept++; }
-        const uint32_t words = W4 ? 32u : 16u;
+        const uint32_t QN = s->node_quant;
+        const uint32_t words = (W4 && !QN) ? 32u : 16u;
         free(s->nodes);
         s->nodes = (float *)calloc((size_t)kept * words, 4);
         for (uint32_t i = 0; i < nn; i++) {
@@ -680,6 +741,7 @@ int orc_accel_build(orc_scene *s) {
                 else slots[ns++] = ch;
             }
             float *nd = s->nodes + (size_t)words * newidx[i];
+            float qmn[4][3], qmx[4][3]; uint32_t qref[4];
             for (uint32_t k = 0; k < (W4 ? 4u : 2u); k++) {
                 float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
                 uint32_t ref = 0xFFFFFFFFu;
@@ -691,9 +753,11 @@ int orc_accel_build(orc_scene *s) {
                         ref = ORC_LIVE(ch) ? newidx[ch] : (0x80000000u | ((rcnt[ch] - 1u) << 28) | rlo[ch]);
                     }
                 }
-                if (W4) { memcpy(nd + 8 * k, mn, 12); memcpy(nd + 8 * k + 3, mx, 12); nd[8 * k + 6] = u2f(ref); nd[8 * k + 7] = 0.0f; }
+                if (QN) { memcpy(qmn[k], mn, 12); memcpy(qmx[k], mx, 12); qref[k] = ref; }
+                else if (W4) { memcpy(nd + 8 * k, mn, 12); memcpy(nd + 8 * k + 3, mx, 12); nd[8 * k + 6] = u2f(ref); nd[8 * k + 7] = 0.0f; }
                 else { memcpy(nd + 6 * k, mn, 12); memcpy(nd + 6 * k + 3, mx, 12); nd[12 + k] = u2f(ref); }
             }
+            if (QN) quantize_node(qmn, qmx, qref, ns, (uint32_t *)nd);
             uint32_t lvl = (W4 ? depth[i] / 2u : depth[i]) + 2u; /* levels from the root to this node's leaf slots */
             if (!W4) { /* binary: collapsed ancestors do not exist, every live ancestor is a level */ }
             if (lvl > maxd) maxd = lvl;
@@ -782,10 +846,13 @@ static void traverse(const orc_scene *s, const float o[3], const float d[3], flo
             nn++;
             uint32_t ref[4]; float tn[4]; int nh = 0;
             if (W4) {
-                const float *nd = s->nodes + 32 * (size_t)cur;
+                const int QN = (int)s->node_quant;
+                const float *nd = s->nodes + (QN ? 16 : 32) * (size_t)cur;
                 for (int k = 0; k < 4; k++) {
-                    uint32_t r = f2u(nd[8 * k + 6]); float t;
-                    if (r != ORC_EMPTY && slab(nd + 8 * k, o, inv, tmin, best.t, &t)) {
+                    float qbox[6];
+                    uint32_t r = QN ? ((const uint32_t *)nd)[10 + k] : f2u(nd[8 * k + 6]); float t;
+                    if (QN && r != ORC_EMPTY) dequantize_slot((const uint32_t *)nd, k, qbox);
+                    if (r != ORC_EMPTY && slab(QN ? qbox : nd + 8 * k, o, inv, tmin, best.t, &t)) {
                         int p = nh++;
                         while (p > 0 && t < tn[p - 1]) { tn[p] = tn[p - 1]; ref[p] = ref[p - 1]; p--; } /* stable: ties keep slot order */
                         tn[p] = t; ref[p] = r;

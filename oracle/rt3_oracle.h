@@ -102,8 +102,9 @@ int orc_scene_set_geometry(orc_scene *s, const orc_geometry_info *g, const uint3
 int orc_scene_set_sky(orc_scene *s, const float *rgb, uint32_t w, uint32_t h);
 int orc_scene_set_bluenoise(orc_scene *s, const uint8_t *rgba, uint32_t w, uint32_t h);
 /* LBVH (Karras 2012) over all triangles; replaces raytracing.rs:88-148 */
-/* leaf_max 1..8 triangles per leaf (default 2); node_width 2 = 64 B binary nodes, 4 = 128 B four-wide nodes (default) */
-void orc_accel_set_layout(orc_scene *s, uint32_t leaf_max, uint32_t node_width);
+/* leaf_max 1..8 triangles per leaf (default 2); node_width 2 = 64 B binary nodes, 4 = four-wide nodes (default);
+ * quantized (width 4 only): 64 B nodes with 8-bit conservative child boxes instead of 128 B fp32 boxes */
+void orc_accel_set_layout(orc_scene *s, uint32_t leaf_max, uint32_t node_width, uint32_t quantized);
 uint32_t orc_accel_node_words(const orc_scene *s);
 int orc_accel_build(orc_scene *s);
 uint32_t orc_accel_num_tris(const orc_scene *s);

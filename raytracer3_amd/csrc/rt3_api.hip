@@ -85,8 +85,8 @@ struct rt3_ctx {
     // options / stats
     int64_t opt_batch_spp = 0;
     bool opt_profile = false, opt_count = false;
-    int opt_variant = 0;
-    uint32_t opt_leaf_size = 2, opt_node_width = 4;
+    int opt_variant = 0;  // RT3_OPT_EXTEND_VARIANT: reserved for traversal experiments
+    uint32_t opt_leaf_size = 2, opt_node_width = 4, opt_node_quant = 1;
     rt3_stats stats;
     uint64_t primary_rays_pending = 0;
     std::vector<Timed> pending_events;
@@ -334,7 +334,7 @@ int pass_gbuffer(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y, const 
     }
     {
         ScopedTimer t(c, CAT_EXTEND);
-        launch_extend(c->stream, c->opt_count, c->bvh.node_bytes == 128, c->bvh.nodes, c->bvh.tris, c->rays[0], S, nullptr, pl->count, pl->count, c->hits, nullptr, nullptr,
+        launch_extend(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->rays[0], S, nullptr, pl->count, pl->count, c->hits, nullptr, nullptr,
                       c->opt_count ? c->d_totals : nullptr);
     }
     c->primary_rays_pending += pl->count;
@@ -400,12 +400,12 @@ int pass_reference_mode(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y,
             cur ^= 1;
             if (nee) {
                 ScopedTimer t(c, CAT_SHADOW);
-                launch_shadow(c->stream, c->opt_count, c->bvh.node_bytes == 128, c->bvh.nodes, c->bvh.tris, c->sh_rays, S, sh_cnt + bn, 0, n_first, c->sh_contrib, c->sh_pid,
+                launch_shadow(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->sh_rays, S, sh_cnt + bn, 0, n_first, c->sh_contrib, c->sh_pid,
                               c->lacc, S, nullptr, nullptr, nullptr, c->opt_count ? c->d_totals + 2 : nullptr);
             }
             if (bn != B - 1) {
                 ScopedTimer t(c, CAT_EXTEND);
-                launch_extend(c->stream, c->opt_count, c->bvh.node_bytes == 128, c->bvh.nodes, c->bvh.tris, c->rays[cur], S, ext_cnt + bn, 0, n_first, c->hits, nullptr, nullptr,
+                launch_extend(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->rays[cur], S, ext_cnt + bn, 0, n_first, c->hits, nullptr, nullptr,
                               c->opt_count ? c->d_totals : nullptr);
             }
         }
@@ -506,6 +506,10 @@ int rt3_set_option(rt3_ctx* c, int option, int64_t value) {
         case RT3_OPT_LEAF_SIZE:
             if (value < 1 || value > 8) return fail(c, RT3_E_INVALID, "leaf size must be 1..8");
             c->opt_leaf_size = (uint32_t)value;
+            c->accel_built = false;
+            return RT3_OK;
+        case RT3_OPT_NODE_QUANT:
+            c->opt_node_quant = value != 0;
             c->accel_built = false;
             return RT3_OK;
         case RT3_OPT_NODE_WIDTH:
@@ -664,7 +668,7 @@ int rt3_accel_build(rt3_ctx* c, uint32_t* out_handle) {
     dev_free(c->bvh.tris);
     dev_free(c->bvh.tri_shade);
     hipError_t e = lbvh_build(c->stream, c->d_verts, c->d_indices, c->d_geoms, c->d_prim_geom, c->d_first_prim, c->n_prims, c->opt_leaf_size,
-                              c->opt_node_width, &c->bvh);
+                              c->opt_node_width, c->opt_node_quant, &c->bvh);
     if (e != hipSuccess) return fail(c, RT3_E_HIP, std::string("lbvh_build: ") + hipGetErrorString(e));
     // worst-case stack use of the near-first walk: (children per node - 1) entries per level above the leaves
     const uint32_t stack_need = c->bvh.max_depth > 1 ? (c->opt_node_width - 1) * (c->bvh.max_depth - 1) : 0;
@@ -875,9 +879,9 @@ int rt3_trace_rays(rt3_ctx* c, const float* rays, uint32_t n, int any_hit, float
     if (repeat < 1) repeat = 1;
     auto launch = [&]() {
         if (any_hit)
-            launch_shadow(c->stream, count, c->bvh.node_bytes == 128, c->bvh.nodes, c->bvh.tris, d_rays, n, nullptr, n, n, nullptr, nullptr, nullptr, 0, d_occ, d_cn, d_ct, nullptr);
+            launch_shadow(c->stream, count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, d_rays, n, nullptr, n, n, nullptr, nullptr, nullptr, 0, d_occ, d_cn, d_ct, nullptr);
         else
-            launch_extend(c->stream, count, c->bvh.node_bytes == 128, c->bvh.nodes, c->bvh.tris, d_rays, n, nullptr, n, n, d_hits, d_cn, d_ct, nullptr);
+            launch_extend(c->stream, count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, d_rays, n, nullptr, n, n, d_hits, d_cn, d_ct, nullptr);
     };
     launch();  // warm-up (also the result-producing launch)
     TR(hipEventRecord(e0, c->stream));

@@ -421,4 +421,16 @@ RT3_DEV bool slab_test(V3 bmin, V3 bmax, V3 o, V3 inv, float tmin, float tbest, 
     return tn <= tf;
 }
 
+// slab test on the hardware min / max / max3 / min3 instructions.  Same values as slab_test up to the sign of a zero
+// (no NaN can occur: the inverse direction is guarded and finite), hence the same hit / order decisions.
+RT3_DEV bool slab_test_hw(V3 bmin, V3 bmax, V3 o, V3 inv, float tmin, float tbest, float& tn_out) {
+    float ax = (bmin.x - o.x) * inv.x, bx = (bmax.x - o.x) * inv.x;
+    float ay = (bmin.y - o.y) * inv.y, by = (bmax.y - o.y) * inv.y;
+    float az = (bmin.z - o.z) * inv.z, bz = (bmax.z - o.z) * inv.z;
+    float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), tmin));
+    float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), tbest));
+    tn_out = tn;
+    return tn <= tf;
+}
+
 }  // namespace rt3

@@ -15,6 +15,10 @@ namespace rt3 {
 
 constexpr int kExtendBlock = 256;          // threads per traversal workgroup (4 waves)
 constexpr unsigned kExtendMaxBlocks = 2048;  // 256 CUs x 8: grid-stride beyond that
+// traversal node layouts
+constexpr int kLayoutBinary64 = 0;   // 64 B: two fp32 child boxes + two references
+constexpr int kLayoutWide128 = 1;    // 128 B: four {fp32 min, max, ref, pad} slots
+constexpr int kLayoutWide64Q = 2;    // 64 B: origin + power-of-two steps + four 8-bit boxes + four references
 constexpr uint32_t kMaxStack = 64;         // traversal stack entries: LDS short stack (24) + private spill (40)
 
 struct ShadeLaunch {
@@ -44,10 +48,10 @@ struct ShadeLaunch {
 };
 
 void launch_raygen(hipStream_t st, const GConstDev& g, const uint32_t* pixels, uint32_t npix, float* rays, size_t stride);
-void launch_extend(hipStream_t st, bool count, bool wide, const float4* nodes, const float4* tris, const float* rays, size_t stride,
+void launch_extend(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float* rays, size_t stride,
                    const uint32_t* count_ptr, uint32_t count_imm, uint32_t max_n, float* hits, uint32_t* cn, uint32_t* ct,
                    unsigned long long* totals);
-void launch_shadow(hipStream_t st, bool count, bool wide, const float4* nodes, const float4* tris, const float* rays, size_t stride,
+void launch_shadow(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float* rays, size_t stride,
                    const uint32_t* count_ptr, uint32_t count_imm, uint32_t max_n, const float* contrib, const uint32_t* pid, float* lacc,
                    size_t lstride, uint32_t* occluded_out, uint32_t* cn, uint32_t* ct, unsigned long long* totals);
 void launch_gbuffer(hipStream_t st, const SceneDev& sc, const uint32_t* pixels, uint32_t npix, uint32_t width, const float* hits,
@@ -69,11 +73,12 @@ void launch_selftest(hipStream_t st, int op, const uint32_t* in, uint32_t n, uin
 struct LbvhResult {
     float4* nodes = nullptr;   // n_nodes x node_bytes: 64 B {box0, box1, ref0, ref1, pad} or 128 B 4 x {min, max, ref, pad}
     uint32_t node_bytes = 128;
+    int layout = kLayoutWide128;
     float4* tris = nullptr;    // n_tris x 3 float4 (48 B), Morton order
     float4* tri_shade = nullptr;  // n_tris x 4 float4 (64 B), global primitive order: vertex normals + geometry index
     uint32_t n_nodes = 0, n_tris = 0, max_depth = 0;
 };
 hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,
-                      const uint32_t* first_prim, uint32_t n_prims, uint32_t leaf_max, uint32_t node_width, LbvhResult* out);
+                      const uint32_t* first_prim, uint32_t n_prims, uint32_t leaf_max, uint32_t node_width, uint32_t node_quant, LbvhResult* out);
 
 }  // namespace rt3

@@ -66,9 +66,11 @@ __device__ __forceinline__ void tri_test_nb(float4 q0, float4 q1, float4 q2, V3 
 // The walk is latency-bound (dependent fetches through L2 / Infinity Cache), so every step makes exactly ONE memory
 // round trip: a lane first fetches its next item -- the node, or the next triangle(s) of its current leaf -- with one
 // batch of 16-byte loads issued together, and only then branches into box tests or triangle tests.
-template <bool ANY, bool COUNT, bool WIDE>
+template <bool ANY, bool COUNT, int LAYOUT>
 __device__ __forceinline__ Hit traverse(const float4* __restrict__ nodes, const float4* __restrict__ tris, V3 o, V3 d,
                                         float tmin, float tmax, uint32_t* __restrict__ lds, uint32_t& cn, uint32_t& ct) {
+    constexpr bool WIDE = LAYOUT == kLayoutWide128;      // 8 x 16 B per fetch
+    constexpr bool WIDEQ = LAYOUT == kLayoutWide64Q;     // 4 x 16 B per fetch, quantised boxes
     Hit best{tmax, 0.0f, 0.0f, kMiss};
     if (nodes == nullptr) return best;
     const V3 inv = v3(guarded_inverse(d.x), guarded_inverse(d.y), guarded_inverse(d.z));
@@ -111,14 +113,41 @@ __device__ __forceinline__ Hit traverse(const float4* __restrict__ nodes, const 
             }
         } else {
             if (COUNT) cn++;
-            if (WIDE) {
+            if (WIDE || WIDEQ) {
                 const float kInf = __builtin_huge_valf();
                 float t0, t1, t2, t3;
-                uint32_t r0 = __float_as_uint(q1.z), r1 = __float_as_uint(q3.z), r2 = __float_as_uint(q5.z), r3 = __float_as_uint(q7.z);
-                bool h0 = slab_test(v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), o, inv, tmin, best.t, t0) & (r0 != kEmptySlot);
-                bool h1 = slab_test(v3(q2.x, q2.y, q2.z), v3(q2.w, q3.x, q3.y), o, inv, tmin, best.t, t1) & (r1 != kEmptySlot);
-                bool h2 = slab_test(v3(q4.x, q4.y, q4.z), v3(q4.w, q5.x, q5.y), o, inv, tmin, best.t, t2) & (r2 != kEmptySlot);
-                bool h3 = slab_test(v3(q6.x, q6.y, q6.z), v3(q6.w, q7.x, q7.y), o, inv, tmin, best.t, t3) & (r3 != kEmptySlot);
+                uint32_t r0, r1, r2, r3;
+                bool h0, h1, h2, h3;
+                if (WIDEQ) {
+                    // decode: box = origin + float(q) * 2^(e-127); bytes 6k..6k+5 of words 4..9 hold child k
+                    const V3 org = v3(q0.x, q0.y, q0.z);
+                    const uint32_t ex = __float_as_uint(q0.w);
+                    const V3 sc = v3(__uint_as_float((ex & 0xFFu) << 23), __uint_as_float(((ex >> 8) & 0xFFu) << 23), __uint_as_float(((ex >> 16) & 0xFFu) << 23));
+                    const uint32_t w0 = __float_as_uint(q1.x), w1 = __float_as_uint(q1.y), w2 = __float_as_uint(q1.z), w3 = __float_as_uint(q1.w),
+                                   w4 = __float_as_uint(q2.x), w5 = __float_as_uint(q2.y);
+                    r0 = __float_as_uint(q2.z);
+                    r1 = __float_as_uint(q2.w);
+                    r2 = __float_as_uint(q3.x);
+                    r3 = __float_as_uint(q3.y);
+#define RT3_Q(w, b) ((float)(((w) >> (8 * (b))) & 0xFFu))
+#define RT3_DEQ(lx, ly, lz, hx, hy, hz) \
+    v3(org.x + (lx) * sc.x, org.y + (ly) * sc.y, org.z + (lz) * sc.z), v3(org.x + (hx) * sc.x, org.y + (hy) * sc.y, org.z + (hz) * sc.z)
+                    h0 = slab_test_hw(RT3_DEQ(RT3_Q(w0, 0), RT3_Q(w0, 1), RT3_Q(w0, 2), RT3_Q(w0, 3), RT3_Q(w1, 0), RT3_Q(w1, 1)), o, inv, tmin, best.t, t0) & (r0 != kEmptySlot);
+                    h1 = slab_test_hw(RT3_DEQ(RT3_Q(w1, 2), RT3_Q(w1, 3), RT3_Q(w2, 0), RT3_Q(w2, 1), RT3_Q(w2, 2), RT3_Q(w2, 3)), o, inv, tmin, best.t, t1) & (r1 != kEmptySlot);
+                    h2 = slab_test_hw(RT3_DEQ(RT3_Q(w3, 0), RT3_Q(w3, 1), RT3_Q(w3, 2), RT3_Q(w3, 3), RT3_Q(w4, 0), RT3_Q(w4, 1)), o, inv, tmin, best.t, t2) & (r2 != kEmptySlot);
+                    h3 = slab_test_hw(RT3_DEQ(RT3_Q(w4, 2), RT3_Q(w4, 3), RT3_Q(w5, 0), RT3_Q(w5, 1), RT3_Q(w5, 2), RT3_Q(w5, 3)), o, inv, tmin, best.t, t3) & (r3 != kEmptySlot);
+#undef RT3_Q
+#undef RT3_DEQ
+                } else {
+                    r0 = __float_as_uint(q1.z);
+                    r1 = __float_as_uint(q3.z);
+                    r2 = __float_as_uint(q5.z);
+                    r3 = __float_as_uint(q7.z);
+                    h0 = slab_test_hw(v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), o, inv, tmin, best.t, t0) & (r0 != kEmptySlot);
+                    h1 = slab_test_hw(v3(q2.x, q2.y, q2.z), v3(q2.w, q3.x, q3.y), o, inv, tmin, best.t, t1) & (r1 != kEmptySlot);
+                    h2 = slab_test_hw(v3(q4.x, q4.y, q4.z), v3(q4.w, q5.x, q5.y), o, inv, tmin, best.t, t2) & (r2 != kEmptySlot);
+                    h3 = slab_test_hw(v3(q6.x, q6.y, q6.z), v3(q6.w, q7.x, q7.y), o, inv, tmin, best.t, t3) & (r3 != kEmptySlot);
+                }
                 Cand c0{h0 ? t0 : kInf, h0 ? r0 : kEmptySlot, 0u}, c1{h1 ? t1 : kInf, h1 ? r1 : kEmptySlot, 1u};
                 Cand c2{h2 ? t2 : kInf, h2 ? r2 : kEmptySlot, 2u}, c3{h3 ? t3 : kInf, h3 ? r3 : kEmptySlot, 3u};
                 const uint32_t nh = (uint32_t)h0 + (uint32_t)h1 + (uint32_t)h2 + (uint32_t)h3;
@@ -148,8 +177,8 @@ __device__ __forceinline__ Hit traverse(const float4* __restrict__ nodes, const 
             } else {
                 float tn0, tn1;
                 uint32_t r0 = __float_as_uint(q3.x), r1 = __float_as_uint(q3.y);
-                bool h0 = slab_test(v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), o, inv, tmin, best.t, tn0) & (r0 != kEmptySlot);
-                bool h1 = slab_test(v3(q1.z, q1.w, q2.x), v3(q2.y, q2.z, q2.w), o, inv, tmin, best.t, tn1) & (r1 != kEmptySlot);
+                bool h0 = slab_test_hw(v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), o, inv, tmin, best.t, tn0) & (r0 != kEmptySlot);
+                bool h1 = slab_test_hw(v3(q1.z, q1.w, q2.x), v3(q2.y, q2.z, q2.w), o, inv, tmin, best.t, tn1) & (r1 != kEmptySlot);
                 bool near1 = tn1 < tn0;
                 if (h0 & h1) {
                     uint32_t far = near1 ? r0 : r1;
@@ -177,7 +206,7 @@ __device__ __forceinline__ Hit traverse(const float4* __restrict__ nodes, const 
 }
 
 // closest-hit over a ray queue.  rays: 8 SoA streams of `stride` floats; hits: t,u,v,prim streams of `stride`.
-template <bool COUNT, bool WIDE>
+template <bool COUNT, int LAYOUT>
 __global__ __launch_bounds__(kExtendBlock) void k_extend(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                                          const float* __restrict__ rays, size_t stride,
                                                          const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
@@ -191,7 +220,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(const float4* __restric
         V3 d = v3(rays[3 * stride + i], rays[4 * stride + i], rays[5 * stride + i]);
         float tmin = rays[6 * stride + i], tmax = rays[7 * stride + i];
         uint32_t cn = 0, ct = 0;
-        Hit h = traverse<false, COUNT, WIDE>(nodes, tris, o, d, tmin, tmax, stack + threadIdx.x, cn, ct);
+        Hit h = traverse<false, COUNT, LAYOUT>(nodes, tris, o, d, tmin, tmax, stack + threadIdx.x, cn, ct);
         hits[i] = h.t;
         hits[stride + i] = h.u;
         hits[2 * stride + i] = h.v;
@@ -211,7 +240,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(const float4* __restric
 
 // any-hit over the shadow queue; unoccluded rays add their contribution to the path's radiance slot.
 // If `occluded_out` != nullptr the kernel only reports occlusion (rt3_trace_rays).
-template <bool COUNT, bool WIDE>
+template <bool COUNT, int LAYOUT>
 __global__ __launch_bounds__(kExtendBlock) void k_shadow(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                                          const float* __restrict__ rays, size_t stride,
                                                          const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
@@ -227,7 +256,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_shadow(const float4* __restric
         V3 d = v3(rays[3 * stride + i], rays[4 * stride + i], rays[5 * stride + i]);
         float tmin = rays[6 * stride + i], tmax = rays[7 * stride + i];
         uint32_t cn = 0, ct = 0;
-        Hit h = traverse<true, COUNT, WIDE>(nodes, tris, o, d, tmin, tmax, stack + threadIdx.x, cn, ct);
+        Hit h = traverse<true, COUNT, LAYOUT>(nodes, tris, o, d, tmin, tmax, stack + threadIdx.x, cn, ct);
         if (occluded_out) {
             occluded_out[i] = h.prim != kMiss ? 1u : 0u;
         } else if (h.prim == kMiss) {
@@ -696,29 +725,39 @@ static inline unsigned grid_for(uint64_t n, unsigned block, unsigned max_blocks)
 void launch_raygen(hipStream_t st, const GConstDev& g, const uint32_t* pixels, uint32_t npix, float* rays, size_t stride) {
     hipLaunchKernelGGL(k_raygen, dim3(grid_for(npix, 256, 4096)), dim3(256), 0, st, g, pixels, npix, rays, stride);
 }
-void launch_extend(hipStream_t st, bool count, bool wide, const float4* nodes, const float4* tris, const float* rays, size_t stride,
+void launch_extend(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float* rays, size_t stride,
                    const uint32_t* count_ptr, uint32_t count_imm, uint32_t max_n, float* hits, uint32_t* cn, uint32_t* ct,
                    unsigned long long* totals) {
     unsigned grid = grid_for(max_n, kExtendBlock, kExtendMaxBlocks);
-#define RT3_LAUNCH_EXTEND(C, W) \
-    hipLaunchKernelGGL((k_extend<C, W>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, hits, cn, ct, totals)
-    if (count && wide) RT3_LAUNCH_EXTEND(true, true);
-    else if (count) RT3_LAUNCH_EXTEND(true, false);
-    else if (wide) RT3_LAUNCH_EXTEND(false, true);
-    else RT3_LAUNCH_EXTEND(false, false);
+#define RT3_LAUNCH_EXTEND(C, L)                                                                                                                  \
+    hipLaunchKernelGGL((k_extend<C, L>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, hits, cn, ct, totals)
+    if (count) {
+        if (layout == kLayoutWide64Q) RT3_LAUNCH_EXTEND(true, kLayoutWide64Q);
+        else if (layout == kLayoutWide128) RT3_LAUNCH_EXTEND(true, kLayoutWide128);
+        else RT3_LAUNCH_EXTEND(true, kLayoutBinary64);
+    } else {
+        if (layout == kLayoutWide64Q) RT3_LAUNCH_EXTEND(false, kLayoutWide64Q);
+        else if (layout == kLayoutWide128) RT3_LAUNCH_EXTEND(false, kLayoutWide128);
+        else RT3_LAUNCH_EXTEND(false, kLayoutBinary64);
+    }
 #undef RT3_LAUNCH_EXTEND
 }
-void launch_shadow(hipStream_t st, bool count, bool wide, const float4* nodes, const float4* tris, const float* rays, size_t stride,
+void launch_shadow(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float* rays, size_t stride,
                    const uint32_t* count_ptr, uint32_t count_imm, uint32_t max_n, const float* contrib, const uint32_t* pid, float* lacc,
                    size_t lstride, uint32_t* occluded_out, uint32_t* cn, uint32_t* ct, unsigned long long* totals) {
     unsigned grid = grid_for(max_n, kExtendBlock, kExtendMaxBlocks);
-#define RT3_LAUNCH_SHADOW(C, W)                                                                                                                \
-    hipLaunchKernelGGL((k_shadow<C, W>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, contrib, pid, lacc, \
+#define RT3_LAUNCH_SHADOW(C, L)                                                                                                                \
+    hipLaunchKernelGGL((k_shadow<C, L>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, contrib, pid, lacc, \
                        lstride, occluded_out, cn, ct, totals)
-    if (count && wide) RT3_LAUNCH_SHADOW(true, true);
-    else if (count) RT3_LAUNCH_SHADOW(true, false);
-    else if (wide) RT3_LAUNCH_SHADOW(false, true);
-    else RT3_LAUNCH_SHADOW(false, false);
+    if (count) {
+        if (layout == kLayoutWide64Q) RT3_LAUNCH_SHADOW(true, kLayoutWide64Q);
+        else if (layout == kLayoutWide128) RT3_LAUNCH_SHADOW(true, kLayoutWide128);
+        else RT3_LAUNCH_SHADOW(true, kLayoutBinary64);
+    } else {
+        if (layout == kLayoutWide64Q) RT3_LAUNCH_SHADOW(false, kLayoutWide64Q);
+        else if (layout == kLayoutWide128) RT3_LAUNCH_SHADOW(false, kLayoutWide128);
+        else RT3_LAUNCH_SHADOW(false, kLayoutBinary64);
+    }
 #undef RT3_LAUNCH_SHADOW
 }
 void launch_gbuffer(hipStream_t st, const SceneDev& sc, const uint32_t* pixels, uint32_t npix, uint32_t width, const float* hits,

@@ -283,10 +283,62 @@ __device__ __forceinline__ void slot_of(uint32_t ch, const float* lmin, const fl
     }
 }
 
+// 64-byte four-wide node with 8-bit child boxes on a per-axis power-of-two grid anchored at the node's min corner:
+//   float4 0: origin.xyz, exponents ex | ey << 8 | ez << 16      float4 1 + first half of 2: 4 x {qlo.xyz, qhi.xyz} bytes
+//   float4 2 second half + float4 3 first half: the four references
+// Conservative with respect to the decode expression origin + float(q) * scale used by the traversal kernels.
+__device__ void quantize_node(const float (*mn)[3], const float (*mx)[3], const uint32_t* ref, uint32_t ns, float4* out) {
+    uint32_t w[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) w[k] = 0u;
+    uint32_t qb[4][6];
+    for (int a = 0; a < 3; a++) {
+        float lo = mn[0][a], hi = mx[0][a];
+        for (uint32_t k = 1; k < ns; k++) {
+            lo = fmin_sel(lo, mn[k][a]);
+            hi = fmax_sel(hi, mx[k][a]);
+        }
+        w[a] = __float_as_uint(lo);
+        float sdiv = (hi - lo) / 255.0f;
+        uint32_t bits = __float_as_uint(sdiv), e = (bits >> 23) & 0xFFu;
+        if (bits & 0x7FFFFFu) e += 1;
+        if (e < 1) e = 1;
+        for (;;) {  // grow the step until every child fits in 8 bits
+            float scale = __uint_as_float(e << 23);
+            uint32_t worst = 0;
+            for (uint32_t k = 0; k < ns; k++) {
+                float fl = floorf((mn[k][a] - lo) / scale);
+                uint32_t ql = fl > 255.0f ? 255u : (uint32_t)fl;
+                while (ql > 0 && lo + (float)ql * scale > mn[k][a]) ql--;
+                float fh = ceilf((mx[k][a] - lo) / scale);
+                uint32_t qh = fh > 1024.0f ? 1024u : (uint32_t)fh;
+                while (qh < 1024u && lo + (float)qh * scale < mx[k][a]) qh++;
+                worst = qh > worst ? qh : worst;
+                qb[k][a] = ql;
+                qb[k][3 + a] = qh > 255u ? 255u : qh;
+            }
+            if (worst <= 255u) break;
+            e++;
+        }
+        w[3] |= e << (8 * a);
+    }
+    for (uint32_t k = 0; k < 4; k++) {
+        for (int j = 0; j < 6; j++) {
+            uint32_t v = k < ns ? qb[k][j] : (j < 3 ? 255u : 0u);
+            uint32_t byte = 6 * k + j;
+            w[4 + (byte >> 2)] |= v << (8 * (byte & 3u));
+        }
+        w[10 + k] = k < ns ? ref[k] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        out[k] = make_float4(__uint_as_float(w[4 * k]), __uint_as_float(w[4 * k + 1]), __uint_as_float(w[4 * k + 2]), __uint_as_float(w[4 * k + 3]));
+}
+
 // one thread per surviving node: gather its 2 (binary) or 2..4 (wide: internal children are absorbed) child slots
 __global__ void k_emit_nodes(const uint32_t* left, const uint32_t* right, const uint32_t* range_lo, const uint32_t* range_cnt,
                              const uint32_t* keep, const uint32_t* newidx, const float* lmin, const float* lmax, const float* nbox,
-                             uint32_t nn, uint32_t leaf_max, int wide, float4* nodes) {
+                             uint32_t nn, uint32_t leaf_max, int wide, int quant, float4* nodes) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += gridDim.x * blockDim.x) {
         if (!keep[i]) continue;
         uint32_t s0 = left[i], s1 = right[i], s2 = 0xFFFFFFFFu, s3 = 0xFFFFFFFFu;
@@ -308,7 +360,14 @@ __global__ void k_emit_nodes(const uint32_t* left, const uint32_t* right, const 
         const uint32_t o = newidx[i];
         float mn[3], mx[3];
         uint32_t ref;
-        if (wide) {
+        if (wide && quant) {
+            const uint32_t sl[4] = {s0, s1, s2, s3};
+            const uint32_t ns = 2u + (v2 ? 1u : 0u) + (v3 ? 1u : 0u);
+            float qmn[4][3], qmx[4][3];
+            uint32_t qref[4] = {0, 0, 0, 0};
+            for (uint32_t k = 0; k < ns; k++) slot_of(sl[k], lmin, lmax, nbox, range_lo, range_cnt, newidx, leaf_max, qmn[k], qmx[k], qref[k]);
+            quantize_node(qmn, qmx, qref, ns, nodes + 4 * (size_t)o);
+        } else if (wide) {
             const float inf = INFINITY;
             const uint32_t sl[4] = {s0, s1, s2, s3};
             const bool vl[4] = {true, true, v2, v3};
@@ -338,9 +397,17 @@ __global__ void k_emit_nodes(const uint32_t* left, const uint32_t* right, const 
 }
 
 // single-triangle scene: root with the leaf in slot 0 and empty other slots
-__global__ void k_single(const float* lmin, const float* lmax, int wide, float4* nodes) {
+__global__ void k_single(const float* lmin, const float* lmax, int wide, int quant, float4* nodes) {
     const float inf = INFINITY;
-    if (wide) {
+    if (wide && quant) {
+        float qmn[4][3], qmx[4][3];
+        uint32_t qref[4] = {0x80000000u, 0, 0, 0};
+        for (int j = 0; j < 3; j++) {
+            qmn[0][j] = lmin[j];
+            qmx[0][j] = lmax[j];
+        }
+        quantize_node(qmn, qmx, qref, 1, nodes);
+    } else if (wide) {
         nodes[0] = make_float4(lmin[0], lmin[1], lmin[2], lmax[0]);
         nodes[1] = make_float4(lmax[1], lmax[2], __uint_as_float(0x80000000u), 0.0f);
         for (int k = 1; k < 4; k++) {
@@ -365,12 +432,13 @@ __global__ void k_single(const float* lmin, const float* lmax, int wide, float4*
     } while (0)
 
 hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,
-                      const uint32_t* first_prim, uint32_t n, uint32_t leaf_max, uint32_t node_width, LbvhResult* out) {
+                      const uint32_t* first_prim, uint32_t n, uint32_t leaf_max, uint32_t node_width, uint32_t node_quant, LbvhResult* out) {
     hipError_t err = hipSuccess;
     *out = LbvhResult{};
     out->n_tris = n;
-    const int wide = node_width == 4;
-    out->node_bytes = wide ? 128u : 64u;
+    const int wide = node_width == 4, quant = wide && node_quant;
+    out->node_bytes = (wide && !quant) ? 128u : 64u;
+    out->layout = !wide ? kLayoutBinary64 : (quant ? kLayoutWide64Q : kLayoutWide128);
     if (n == 0) return hipSuccess;
     const uint32_t nn = n > 1 ? n - 1 : 1;
     float *bmin = nullptr, *bmax = nullptr, *lmin = nullptr, *lmax = nullptr, *nbox = nullptr;
@@ -424,7 +492,7 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
                        out->tris, lmin, lmax);
     if (n == 1) {
         LB_CHECK(hipMalloc(&out->nodes, out->node_bytes));
-        hipLaunchKernelGGL(k_single, dim3(1), dim3(1), 0, st, lmin, lmax, wide, out->nodes);
+        hipLaunchKernelGGL(k_single, dim3(1), dim3(1), 0, st, lmin, lmax, wide, quant, out->nodes);
         out->n_nodes = 1;
         out->max_depth = 2;
         LB_CHECK(hipGetLastError());
@@ -443,7 +511,7 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
         out->n_nodes = tail[0] + tail[1];
         LB_CHECK(hipMalloc(&out->nodes, (size_t)out->n_nodes * out->node_bytes));
         hipLaunchKernelGGL(k_emit_nodes, dim3(grid), dim3(256), 0, st, left, right, rlo, rcnt, keep, newidx, lmin, lmax, nbox, nn, leaf_max, wide,
-                           out->nodes);
+                           quant, out->nodes);
         LB_CHECK(hipGetLastError());
         LB_CHECK(hipStreamSynchronize(st));
     }

@@ -54,19 +54,20 @@ def test_device_is_gfx950():
     ctx.close()
 
 
-@pytest.mark.parametrize("leaf,width", [(2, 4), (1, 2), (4, 4), (8, 4), (4, 2)])
-def test_lbvh_bit_identical_to_oracle(small, leaf, width):
-    """every layout: 64 B binary / 128 B four-wide nodes x 1..8 triangles per leaf"""
+@pytest.mark.parametrize("leaf,width,quant", [(2, 4, 1), (2, 4, 0), (1, 2, 0), (4, 4, 1), (8, 4, 0), (4, 2, 0), (1, 4, 1)])
+def test_lbvh_bit_identical_to_oracle(small, leaf, width, quant):
+    """every layout: 64 B binary / 128 B four-wide / 64 B quantised four-wide nodes x 1..8 triangles per leaf"""
     mesh, sky, bn, _ = small
-    osc = orc.Scene(mesh, leaf_size=leaf, node_width=width)
+    osc = orc.Scene(mesh, leaf_size=leaf, node_width=width, quantized=quant)
     ctx = Context(0)
     ctx.set_option(L.OPT_LEAF_SIZE, leaf)
     ctx.set_option(L.OPT_NODE_WIDTH, width)
+    ctx.set_option(L.OPT_NODE_QUANT, quant)
     ctx.upload_mesh(mesh)
     handle = ctx.build_accel()
     assert handle >> 30 == L.TAG_ACCEL
     nn, nt, levels, nb = ctx.accel_info()
-    assert (nn, nt, levels, nb) == (osc.n_nodes, osc.n_tris, osc.max_depth, 64 if width == 2 else 128)
+    assert (nn, nt, levels, nb) == (osc.n_nodes, osc.n_tris, osc.max_depth, 64 if (width == 2 or quant) else 128)
     nodes, tris = ctx.accel_download()
     assert np.array_equal(tris, osc.tris())
     assert np.array_equal(nodes, osc.nodes())

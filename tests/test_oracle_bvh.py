@@ -17,7 +17,7 @@ def test_bvh_equals_bruteforce_fp32_and_tracks_fp64():
     mesh = scenes.atrium(0.2)
     sc = orc.Scene(mesh)
     assert sc.n_nodes < sc.n_tris and sc.max_depth < 22
-    base = orc.Scene(mesh, leaf_size=1, node_width=2)  # plain Karras tree: n - 1 binary nodes
+    base = orc.Scene(mesh, leaf_size=1, node_width=2, quantized=0)  # plain Karras tree: n - 1 binary nodes
     assert base.n_nodes == base.n_tris - 1
     codes = sc.codes()
     assert (np.diff(codes.astype(np.float64)) >= 0).all()  # Morton order
@@ -35,8 +35,8 @@ def test_bvh_equals_bruteforce_fp32_and_tracks_fp64():
     occ = sc.trace_any(rays)
     assert np.array_equal(occ != 0, p != orc.MISS)
     # the layout (leaf size, node width) changes the walk, never the answer
-    for leaf, width in ((1, 2), (4, 2), (1, 4), (8, 4)):
-        alt = orc.Scene(mesh, leaf_size=leaf, node_width=width)
+    for leaf, width, quant in ((1, 2, 0), (4, 2, 0), (1, 4, 0), (8, 4, 0), (2, 4, 0), (4, 4, 1)):
+        alt = orc.Scene(mesh, leaf_size=leaf, node_width=width, quantized=quant)
         at, au, av, ap = alt.trace_closest(rays)
         assert np.array_equal(ap, p) and np.array_equal(at, t) and np.array_equal(au, u) and np.array_equal(av, v)
         assert np.array_equal(alt.trace_any(rays) != 0, occ != 0)
