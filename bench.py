@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--leaf-size", type=int, default=0, help="triangles per BVH leaf (0 = library default)")
     ap.add_argument("--node-width", type=int, default=0, help="2 | 4 (0 = library default)")
     ap.add_argument("--node-quant", type=int, default=-1, help="0 | 1 (-1 = library default)")
+    ap.add_argument("--refill", type=int, default=-1, help="traversal tuning: idle lanes before a wave refills (RT3_OPT_EXTEND_VARIANT)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-crop", type=str, default="960x540")
     args = ap.parse_args()
@@ -79,6 +80,8 @@ def main():
         pt.ctx.set_option(L.OPT_NODE_WIDTH, args.node_width)
     if args.node_quant >= 0:
         pt.ctx.set_option(L.OPT_NODE_QUANT, args.node_quant)
+    if args.refill >= 0:
+        pt.ctx.set_option(L.OPT_EXTEND_VARIANT, args.refill)
     pt.set_scene(mesh, sky, bn)
     if args.batch_spp:
         pt.ctx.set_option(L.OPT_BATCH_SPP, args.batch_spp)

@@ -109,7 +109,7 @@ int rt3_device_name(rt3_ctx *ctx, char *buf, size_t buf_size);
 #define RT3_OPT_BATCH_SPP 1       /* samples per wavefront batch (0 = auto) */
 #define RT3_OPT_PROFILE 2         /* 1: bracket kernels with HIP events on the context's stream */
 #define RT3_OPT_COUNT_TRAVERSAL 3 /* 1: k_extend/k_shadow also count nodes / triangles (slower; for roofline bytes) */
-#define RT3_OPT_EXTEND_VARIANT 4  /* reserved for traversal experiments (no effect) */
+#define RT3_OPT_EXTEND_VARIANT 4  /* traversal tuning: idle lanes of a wave before it refills them from its ray pool (default 12) */
 #define RT3_OPT_LEAF_SIZE 5       /* 1..8 triangles per BVH leaf (default 2); takes effect at the next rt3_accel_build */
 #define RT3_OPT_NODE_WIDTH 6      /* 2 = binary nodes, 4 = four-wide nodes (default); next rt3_accel_build */
 #define RT3_OPT_NODE_QUANT 7      /* width 4 only: 1 = 64 B nodes with 8-bit conservative child boxes (default), 0 = 128 B fp32 boxes */

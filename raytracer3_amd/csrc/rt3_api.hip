@@ -502,7 +502,10 @@ int rt3_set_option(rt3_ctx* c, int option, int64_t value) {
         case RT3_OPT_BATCH_SPP: c->opt_batch_spp = value; return RT3_OK;
         case RT3_OPT_PROFILE: c->opt_profile = value != 0; return RT3_OK;
         case RT3_OPT_COUNT_TRAVERSAL: c->opt_count = value != 0; return RT3_OK;
-        case RT3_OPT_EXTEND_VARIANT: c->opt_variant = (int)value; return RT3_OK;
+        case RT3_OPT_EXTEND_VARIANT:
+            c->opt_variant = (int)value;
+            set_refill_lanes((uint32_t)value);
+            return RT3_OK;
         case RT3_OPT_LEAF_SIZE:
             if (value < 1 || value > 8) return fail(c, RT3_E_INVALID, "leaf size must be 1..8");
             c->opt_leaf_size = (uint32_t)value;

@@ -59,29 +59,85 @@ __device__ __forceinline__ void tri_test_nb(float4 q0, float4 q1, float4 q2, V3 
     best.prim = ok ? prim : best.prim;
 }
 
-// One ray per lane.  WIDE: 128 B nodes with four {min, max, ref, pad} slots; else 64 B binary nodes.
+// Persistent-wave traversal.  Every wave owns a contiguous pool of rays.  One ray per lane; a lane that finishes its ray
+// immediately takes the next one from the pool (refill once >= kRefillLanes lanes are idle), so the wave keeps its 64
+// lanes busy instead of idling until its slowest ray is done: the walk is VALU-issue-bound and a plain one-ray-per-lane
+// loop spent ~49 iterations per 64 rays whose mean length is ~23 steps.
+//
+// Layouts: kLayoutBinary64 (two fp32 boxes), kLayoutWide128 (four fp32 boxes), kLayoutWide64Q (four 8-bit boxes).
 // Children are visited nearest first (ties: lower slot); the others are pushed so that they pop in ascending entry
 // distance; no re-cull on pop.  A leaf reference holds 1..8 consecutive triangles.
-//
-// The walk is latency-bound (dependent fetches through L2 / Infinity Cache), so every step makes exactly ONE memory
-// round trip: a lane first fetches its next item -- the node, or the next triangle(s) of its current leaf -- with one
-// batch of 16-byte loads issued together, and only then branches into box tests or triangle tests.
-template <bool ANY, bool COUNT, int LAYOUT>
-__device__ __forceinline__ Hit traverse(const float4* __restrict__ nodes, const float4* __restrict__ tris, V3 o, V3 d,
-                                        float tmin, float tmax, uint32_t* __restrict__ lds, uint32_t& cn, uint32_t& ct) {
-    constexpr bool WIDE = LAYOUT == kLayoutWide128;      // 8 x 16 B per fetch
-    constexpr bool WIDEQ = LAYOUT == kLayoutWide64Q;     // 4 x 16 B per fetch, quantised boxes
-    Hit best{tmax, 0.0f, 0.0f, kMiss};
-    if (nodes == nullptr) return best;
-    const V3 inv = v3(guarded_inverse(d.x), guarded_inverse(d.y), guarded_inverse(d.z));
+// Every step makes exactly ONE memory round trip: a lane first fetches its next item -- the node, or the next
+// triangle(s) of its current leaf -- with one batch of 16-byte loads issued together, then branches into box or
+// triangle tests (both branch-free).
+__constant__ uint32_t g_refill_lanes = 12;  // tuning knob (RT3_OPT_EXTEND_VARIANT)
+void set_refill_lanes(uint32_t v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_refill_lanes), &v, 4); }
+
+struct LaneRay {  // traversal state of the ray a lane currently owns
+    V3 o, d, inv;
+    float tmin;
+    Hit best;
+    uint32_t cur, leaf_k, index, steps, cn, ct;
+    int sp;
+};
+
+template <bool ANY, bool COUNT, int LAYOUT, typename Finish>
+__device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, const float4* __restrict__ tris,
+                                             const float* __restrict__ rays, size_t stride, uint32_t n, uint32_t* __restrict__ lds,
+                                             Finish finish) {
+    constexpr bool WIDE = LAYOUT == kLayoutWide128;   // 8 x 16 B per fetch
+    constexpr bool WIDEQ = LAYOUT == kLayoutWide64Q;  // 4 x 16 B per fetch, quantised boxes
+    // this wave's pool: a contiguous, 64-aligned slice of the queue
+    const uint32_t waves_total = gridDim.x * (kExtendBlock / 64), wave_id = blockIdx.x * (kExtendBlock / 64) + (threadIdx.x >> 6);
+    const uint32_t per_wave = (((n + waves_total - 1) / waves_total) + 63u) & ~63u;
+    uint32_t pool_next = wave_id * per_wave < n ? wave_id * per_wave : n;
+    const uint32_t pool_end = pool_next + per_wave < n ? pool_next + per_wave : n;
+    const uint32_t lane = __lane_id();
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    const uint32_t kRefillLanes = g_refill_lanes;
     uint32_t spill[kSpill];
-    int sp = 0;
-    uint32_t cur = 0, leaf_k = 0;
-    // kMaxSteps bounds the walk so that a corrupt tree can never hang the GPU (a valid tree visits < 2 n nodes)
-    for (uint32_t step = 0; step < kMaxSteps; ++step) {
-        const bool is_leaf = (cur & 0x80000000u) != 0u;
-        const uint32_t first = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u;
-        const float4* p = is_leaf ? tris + 3 * (size_t)(first + leaf_k) : nodes + (WIDE ? 8 : 4) * (size_t)cur;
+    LaneRay r;
+    r.o = r.d = r.inv = v3(0.0f, 0.0f, 0.0f);
+    r.tmin = 0.0f;
+    r.best = Hit{0.0f, 0.0f, 0.0f, kMiss};
+    r.cur = r.leaf_k = r.index = r.steps = r.cn = r.ct = 0u;
+    r.sp = 0;
+    bool busy = false;
+    for (;;) {
+        // ---- refill idle lanes from the pool
+        const unsigned long long m_idle = __ballot(!busy);
+        if (m_idle != 0ull && pool_next < pool_end && ((uint32_t)__popcll(m_idle) >= kRefillLanes || m_idle == ~0ull)) {
+            const uint32_t idx = pool_next + (uint32_t)__popcll(m_idle & lanes_below);
+            if (!busy && idx < pool_end) {
+                r.o = v3(rays[idx], rays[stride + idx], rays[2 * stride + idx]);
+                r.d = v3(rays[3 * stride + idx], rays[4 * stride + idx], rays[5 * stride + idx]);
+                r.tmin = rays[6 * stride + idx];
+                r.best = Hit{rays[7 * stride + idx], 0.0f, 0.0f, kMiss};
+                r.inv = v3(guarded_inverse(r.d.x), guarded_inverse(r.d.y), guarded_inverse(r.d.z));
+                r.cur = 0u;
+                r.leaf_k = 0u;
+                r.sp = 0;
+                r.index = idx;
+                r.steps = 0u;
+                r.cn = r.ct = 0u;
+                busy = true;
+                if (nodes == nullptr) {  // empty scene: everything misses
+                    finish(r.index, r.best, 0u, 0u);
+                    busy = false;
+                }
+            }
+            const uint32_t taken = (uint32_t)__popcll(m_idle);
+            pool_next = pool_next + taken < pool_end ? pool_next + taken : pool_end;
+        }
+        if (__ballot(busy) == 0ull) {
+            if (pool_next >= pool_end) break;
+            continue;
+        }
+        if (!busy) continue;
+        // ---- one traversal step
+        const bool is_leaf = (r.cur & 0x80000000u) != 0u;
+        const uint32_t first = r.cur & 0x0FFFFFFFu, cnt = ((r.cur >> 28) & 7u) + 1u;
+        const float4* p = is_leaf ? tris + 3 * (size_t)(first + r.leaf_k) : nodes + (WIDE ? 8 : 4) * (size_t)r.cur;
         // one batch of loads (the triangle array carries 128 B of slack so that over-reading a leaf is in bounds)
         float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4, q5, q6, q7;
         if (WIDE) {
@@ -94,25 +150,27 @@ __device__ __forceinline__ Hit traverse(const float4* __restrict__ nodes, const 
         // turns one memory round trip per step into two
         pin(q0); pin(q1); pin(q2); pin(q3);
         if (WIDE) { pin(q4); pin(q5); pin(q6); pin(q7); }
-        bool pop = false;
+        bool pop = false, done = false;
+        const V3 o = r.o, d = r.d, inv = r.inv;
+        const float tmin = r.tmin;
         if (is_leaf) {
-            if (COUNT) ct++;
-            tri_test_nb(q0, q1, q2, o, d, tmin, best);
-            leaf_k++;
+            if (COUNT) r.ct++;
+            tri_test_nb(q0, q1, q2, o, d, tmin, r.best);
+            r.leaf_k++;
             if (WIDE) {  // the 128 B fetch holds a second triangle
-                if (leaf_k < cnt && !(ANY && best.prim != kMiss)) {
-                    if (COUNT) ct++;
-                    tri_test_nb(q3, q4, q5, o, d, tmin, best);
-                    leaf_k++;
+                if (r.leaf_k < cnt && !(ANY && r.best.prim != kMiss)) {
+                    if (COUNT) r.ct++;
+                    tri_test_nb(q3, q4, q5, o, d, tmin, r.best);
+                    r.leaf_k++;
                 }
             }
-            if (ANY && best.prim != kMiss) break;
-            if (leaf_k >= cnt) {
-                leaf_k = 0;
+            if (ANY && r.best.prim != kMiss) done = true;
+            if (r.leaf_k >= cnt) {
+                r.leaf_k = 0;
                 pop = true;
             }
         } else {
-            if (COUNT) cn++;
+            if (COUNT) r.cn++;
             if (WIDE || WIDEQ) {
                 const float kInf = __builtin_huge_valf();
                 float t0, t1, t2, t3;
@@ -132,10 +190,10 @@ __device__ __forceinline__ Hit traverse(const float4* __restrict__ nodes, const 
 #define RT3_Q(w, b) ((float)(((w) >> (8 * (b))) & 0xFFu))
 #define RT3_DEQ(lx, ly, lz, hx, hy, hz) \
     v3(org.x + (lx) * sc.x, org.y + (ly) * sc.y, org.z + (lz) * sc.z), v3(org.x + (hx) * sc.x, org.y + (hy) * sc.y, org.z + (hz) * sc.z)
-                    h0 = slab_test_hw(RT3_DEQ(RT3_Q(w0, 0), RT3_Q(w0, 1), RT3_Q(w0, 2), RT3_Q(w0, 3), RT3_Q(w1, 0), RT3_Q(w1, 1)), o, inv, tmin, best.t, t0) & (r0 != kEmptySlot);
-                    h1 = slab_test_hw(RT3_DEQ(RT3_Q(w1, 2), RT3_Q(w1, 3), RT3_Q(w2, 0), RT3_Q(w2, 1), RT3_Q(w2, 2), RT3_Q(w2, 3)), o, inv, tmin, best.t, t1) & (r1 != kEmptySlot);
-                    h2 = slab_test_hw(RT3_DEQ(RT3_Q(w3, 0), RT3_Q(w3, 1), RT3_Q(w3, 2), RT3_Q(w3, 3), RT3_Q(w4, 0), RT3_Q(w4, 1)), o, inv, tmin, best.t, t2) & (r2 != kEmptySlot);
-                    h3 = slab_test_hw(RT3_DEQ(RT3_Q(w4, 2), RT3_Q(w4, 3), RT3_Q(w5, 0), RT3_Q(w5, 1), RT3_Q(w5, 2), RT3_Q(w5, 3)), o, inv, tmin, best.t, t3) & (r3 != kEmptySlot);
+                    h0 = slab_test_hw(RT3_DEQ(RT3_Q(w0, 0), RT3_Q(w0, 1), RT3_Q(w0, 2), RT3_Q(w0, 3), RT3_Q(w1, 0), RT3_Q(w1, 1)), o, inv, tmin, r.best.t, t0) & (r0 != kEmptySlot);
+                    h1 = slab_test_hw(RT3_DEQ(RT3_Q(w1, 2), RT3_Q(w1, 3), RT3_Q(w2, 0), RT3_Q(w2, 1), RT3_Q(w2, 2), RT3_Q(w2, 3)), o, inv, tmin, r.best.t, t1) & (r1 != kEmptySlot);
+                    h2 = slab_test_hw(RT3_DEQ(RT3_Q(w3, 0), RT3_Q(w3, 1), RT3_Q(w3, 2), RT3_Q(w3, 3), RT3_Q(w4, 0), RT3_Q(w4, 1)), o, inv, tmin, r.best.t, t2) & (r2 != kEmptySlot);
+                    h3 = slab_test_hw(RT3_DEQ(RT3_Q(w4, 2), RT3_Q(w4, 3), RT3_Q(w5, 0), RT3_Q(w5, 1), RT3_Q(w5, 2), RT3_Q(w5, 3)), o, inv, tmin, r.best.t, t3) & (r3 != kEmptySlot);
 #undef RT3_Q
 #undef RT3_DEQ
                 } else {
@@ -143,10 +201,10 @@ __device__ __forceinline__ Hit traverse(const float4* __restrict__ nodes, const 
                     r1 = __float_as_uint(q3.z);
                     r2 = __float_as_uint(q5.z);
                     r3 = __float_as_uint(q7.z);
-                    h0 = slab_test_hw(v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), o, inv, tmin, best.t, t0) & (r0 != kEmptySlot);
-                    h1 = slab_test_hw(v3(q2.x, q2.y, q2.z), v3(q2.w, q3.x, q3.y), o, inv, tmin, best.t, t1) & (r1 != kEmptySlot);
-                    h2 = slab_test_hw(v3(q4.x, q4.y, q4.z), v3(q4.w, q5.x, q5.y), o, inv, tmin, best.t, t2) & (r2 != kEmptySlot);
-                    h3 = slab_test_hw(v3(q6.x, q6.y, q6.z), v3(q6.w, q7.x, q7.y), o, inv, tmin, best.t, t3) & (r3 != kEmptySlot);
+                    h0 = slab_test_hw(v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), o, inv, tmin, r.best.t, t0) & (r0 != kEmptySlot);
+                    h1 = slab_test_hw(v3(q2.x, q2.y, q2.z), v3(q2.w, q3.x, q3.y), o, inv, tmin, r.best.t, t1) & (r1 != kEmptySlot);
+                    h2 = slab_test_hw(v3(q4.x, q4.y, q4.z), v3(q4.w, q5.x, q5.y), o, inv, tmin, r.best.t, t2) & (r2 != kEmptySlot);
+                    h3 = slab_test_hw(v3(q6.x, q6.y, q6.z), v3(q6.w, q7.x, q7.y), o, inv, tmin, r.best.t, t3) & (r3 != kEmptySlot);
                 }
                 Cand c0{h0 ? t0 : kInf, h0 ? r0 : kEmptySlot, 0u}, c1{h1 ? t1 : kInf, h1 ? r1 : kEmptySlot, 1u};
                 Cand c2{h2 ? t2 : kInf, h2 ? r2 : kEmptySlot, 2u}, c3{h3 ? t3 : kInf, h3 ? r3 : kEmptySlot, 3u};
@@ -158,51 +216,59 @@ __device__ __forceinline__ Hit traverse(const float4* __restrict__ nodes, const 
                 cswap(c1, c3);
                 cswap(c1, c2);
                 if (nh > 3) {
-                    if (sp < kLdsStack) lds[sp * kExtendBlock] = c3.ref;
-                    else spill[sp - kLdsStack] = c3.ref;
-                    ++sp;
+                    if (r.sp < kLdsStack) lds[r.sp * kExtendBlock] = c3.ref;
+                    else spill[r.sp - kLdsStack] = c3.ref;
+                    ++r.sp;
                 }
                 if (nh > 2) {
-                    if (sp < kLdsStack) lds[sp * kExtendBlock] = c2.ref;
-                    else spill[sp - kLdsStack] = c2.ref;
-                    ++sp;
+                    if (r.sp < kLdsStack) lds[r.sp * kExtendBlock] = c2.ref;
+                    else spill[r.sp - kLdsStack] = c2.ref;
+                    ++r.sp;
                 }
                 if (nh > 1) {
-                    if (sp < kLdsStack) lds[sp * kExtendBlock] = c1.ref;
-                    else spill[sp - kLdsStack] = c1.ref;
-                    ++sp;
+                    if (r.sp < kLdsStack) lds[r.sp * kExtendBlock] = c1.ref;
+                    else spill[r.sp - kLdsStack] = c1.ref;
+                    ++r.sp;
                 }
-                cur = c0.ref;
+                r.cur = c0.ref;
                 pop = nh == 0;
             } else {
                 float tn0, tn1;
                 uint32_t r0 = __float_as_uint(q3.x), r1 = __float_as_uint(q3.y);
-                bool h0 = slab_test_hw(v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), o, inv, tmin, best.t, tn0) & (r0 != kEmptySlot);
-                bool h1 = slab_test_hw(v3(q1.z, q1.w, q2.x), v3(q2.y, q2.z, q2.w), o, inv, tmin, best.t, tn1) & (r1 != kEmptySlot);
+                bool h0 = slab_test_hw(v3(q0.x, q0.y, q0.z), v3(q0.w, q1.x, q1.y), o, inv, tmin, r.best.t, tn0) & (r0 != kEmptySlot);
+                bool h1 = slab_test_hw(v3(q1.z, q1.w, q2.x), v3(q2.y, q2.z, q2.w), o, inv, tmin, r.best.t, tn1) & (r1 != kEmptySlot);
                 bool near1 = tn1 < tn0;
                 if (h0 & h1) {
                     uint32_t far = near1 ? r0 : r1;
-                    if (sp < kLdsStack) lds[sp * kExtendBlock] = far;
-                    else spill[sp - kLdsStack] = far;
-                    ++sp;
+                    if (r.sp < kLdsStack) lds[r.sp * kExtendBlock] = far;
+                    else spill[r.sp - kLdsStack] = far;
+                    ++r.sp;
                 }
-                cur = (h0 & h1) ? (near1 ? r1 : r0) : (h0 ? r0 : r1);
+                r.cur = (h0 & h1) ? (near1 ? r1 : r0) : (h0 ? r0 : r1);
                 pop = !(h0 | h1);
             }
         }
-        if (pop) {
-            if (sp == 0) break;
-            --sp;
-            // two explicit paths: a pointer select here would turn the pop into a flat_load
-            if (sp < kLdsStack) {
-                cur = lds[sp * kExtendBlock];
+        if (pop && !done) {
+            if (r.sp == 0) {
+                done = true;
             } else {
-                cur = spill[sp - kLdsStack];
-                __builtin_amdgcn_sched_barrier(0);
+                --r.sp;
+                // two explicit paths: a pointer select here would turn the pop into a flat_load
+                if (r.sp < kLdsStack) {
+                    r.cur = lds[r.sp * kExtendBlock];
+                } else {
+                    r.cur = spill[r.sp - kLdsStack];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
+        // kMaxSteps bounds the walk so that a corrupt tree can never hang the GPU (a valid tree visits < 2 n nodes)
+        if (++r.steps >= kMaxSteps) done = true;
+        if (done) {
+            finish(r.index, r.best, r.cn, r.ct);
+            busy = false;
+        }
     }
-    return best;
 }
 
 // closest-hit over a ray queue.  rays: 8 SoA streams of `stride` floats; hits: t,u,v,prim streams of `stride`.
@@ -215,12 +281,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(const float4* __restric
     __shared__ uint32_t stack[kLdsStack * kExtendBlock];
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
     unsigned long long tot_n = 0, tot_t = 0;
-    for (uint32_t i = blockIdx.x * kExtendBlock + threadIdx.x; i < n; i += gridDim.x * kExtendBlock) {
-        V3 o = v3(rays[i], rays[stride + i], rays[2 * stride + i]);
-        V3 d = v3(rays[3 * stride + i], rays[4 * stride + i], rays[5 * stride + i]);
-        float tmin = rays[6 * stride + i], tmax = rays[7 * stride + i];
-        uint32_t cn = 0, ct = 0;
-        Hit h = traverse<false, COUNT, LAYOUT>(nodes, tris, o, d, tmin, tmax, stack + threadIdx.x, cn, ct);
+    trace_stream<false, COUNT, LAYOUT>(nodes, tris, rays, stride, n, stack + threadIdx.x, [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct) {
         hits[i] = h.t;
         hits[stride + i] = h.u;
         hits[2 * stride + i] = h.v;
@@ -231,7 +292,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(const float4* __restric
             tot_n += cn;
             tot_t += ct;
         }
-    }
+    });
     if (COUNT && totals) {
         atomicAdd(&totals[0], tot_n);
         atomicAdd(&totals[1], tot_t);
@@ -251,12 +312,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_shadow(const float4* __restric
     __shared__ uint32_t stack[kLdsStack * kExtendBlock];
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
     unsigned long long tot_n = 0, tot_t = 0;
-    for (uint32_t i = blockIdx.x * kExtendBlock + threadIdx.x; i < n; i += gridDim.x * kExtendBlock) {
-        V3 o = v3(rays[i], rays[stride + i], rays[2 * stride + i]);
-        V3 d = v3(rays[3 * stride + i], rays[4 * stride + i], rays[5 * stride + i]);
-        float tmin = rays[6 * stride + i], tmax = rays[7 * stride + i];
-        uint32_t cn = 0, ct = 0;
-        Hit h = traverse<true, COUNT, LAYOUT>(nodes, tris, o, d, tmin, tmax, stack + threadIdx.x, cn, ct);
+    trace_stream<true, COUNT, LAYOUT>(nodes, tris, rays, stride, n, stack + threadIdx.x, [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct) {
         if (occluded_out) {
             occluded_out[i] = h.prim != kMiss ? 1u : 0u;
         } else if (h.prim == kMiss) {
@@ -271,7 +327,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_shadow(const float4* __restric
             tot_n += cn;
             tot_t += ct;
         }
-    }
+    });
     if (COUNT && totals) {
         atomicAdd(&totals[0], tot_n);
         atomicAdd(&totals[1], tot_t);
