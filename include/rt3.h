@@ -48,7 +48,7 @@ extern "C" {
  * 2 random draws per bounce, refrence_mode.slang:36-57).  The others are north_star additions. */
 #define RT3_F_NEE_SKY 1u     /* next-event estimation + MIS against the equirect sky */
 #define RT3_F_BLUENOISE 2u   /* Cranley-Patterson shift by resources/bluenoise.png */
-#define RT3_F_SPECULAR 4u    /* reserved: layered GGX (brdf.slang:141-311) */
+#define RT3_F_SPECULAR 4u    /* layered BSDF: DiffuseBrdf under the GGX SpecularBrdf of brdf.slang:141-311 */
 #define RT3_F_FACEFORWARD 8u /* flip the shading normal towards the incoming ray */
 
 /* src/renderer/mod.rs:47-63 == shaders/include/datatypes.slang:28-43.  304 bytes, 16-byte aligned, column-major

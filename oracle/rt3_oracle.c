@@ -1039,6 +1039,96 @@ static inline float bn_shift(float u, uint32_t c) {
     return r >= 1.0f ? r - 1.0f : r;
 }
 
+/* ------------------------------------------------------------------------------------------------ layered BSDF */
+/* [north_star "BSDF eval"] DiffuseBrdf (brdf.slang:52-93) under a GGX SpecularBrdf (brdf.slang:141-311: VNDF sampling,
+ * height-correlated Smith, Schlick with f90 = 1), combined like the reference's source renderer: f0 = lerp(0.04, albedo,
+ * metalness), diffuse albedo = albedo (1 - metalness), diffuse attenuated by the transmitted fraction (1 - F).  One
+ * lobe is chosen with probability p_spec (luminance ratio, clamped to [0.1, 0.9]) and the sample is weighted by
+ * f / pdf of the mixture (one-sample MIS).  All pdfs are with respect to PROJECTED solid angle like brdf.slang:31;
+ * directions are in the tangent frame (z = shading normal). */
+typedef struct { float da[3], f0[3], alpha, p_spec; } bsdf_t;
+static inline float pow5(float x) { float x2 = x * x; return x2 * x2 * x; }
+static float g_smith_ggx1(float ndotv, float a2) { /* brdf.slang:111-114 */
+    float tan2_v = (1.0f - ndotv * ndotv) / (ndotv * ndotv);
+    return 2.0f / (1.0f + sqrtf(1.0f + a2 * tan2_v));
+}
+static float g_smith_ggx_correlated(float ndotv, float ndotl, float a2) { /* brdf.slang:104-109 */
+    float lambda_v = ndotl * sqrtf((-ndotv * a2 + ndotv) * ndotv + a2);
+    float lambda_l = ndotv * sqrtf((-ndotl * a2 + ndotl) * ndotl + a2);
+    return 2.0f * ndotl * ndotv / (lambda_v + lambda_l);
+}
+static float ggx_ndf(float a2, float cos_theta) { /* brdf.slang:146-149 */
+    float denom_sqrt = cos_theta * cos_theta * (a2 - 1.0f) + 1.0f;
+    return a2 / (F_PI * denom_sqrt * denom_sqrt);
+}
+static void bsdf_setup(const float surf[11], bsdf_t *b) {
+    float m = surf[10];
+    for (int k = 0; k < 3; k++) { b->f0[k] = 0.04f + (surf[k] - 0.04f) * m; b->da[k] = surf[k] * (1.0f - m); }
+    b->alpha = fmaxx(surf[9], 0.05f);
+    float ls = luminance3(b->f0), ld = luminance3(b->da);
+    float p = (ls + ld) > 0.0f ? ls / (ls + ld) : 1.0f;
+    b->p_spec = ld > 0.0f ? fminx(fmaxx(p, 0.1f), 0.9f) : 1.0f;
+}
+/* value (BRDF without the cosine) and mixture pdf (projected solid angle) for wo, wi in the tangent frame */
+static void bsdf_eval(const bsdf_t *b, const float wo[3], const float wi[3], float value[3], float *pdf_proj) {
+    value[0] = value[1] = value[2] = 0.0f; *pdf_proj = 0.0f;
+    if (!(wi[2] > 0.0f)) return;
+    if (!(wo[2] > 1e-5f)) { /* grazing / back-facing view: diffuse only */
+        for (int k = 0; k < 3; k++) value[k] = b->da[k] * F_FRAC_1_PI;
+        *pdf_proj = F_FRAC_1_PI;
+        return;
+    }
+    const float a2 = b->alpha * b->alpha;
+    float h[3] = {wo[0] + wi[0], wo[1] + wi[1], wo[2] + wi[2]};
+    normalize3(h); /* brdf.slang:268 */
+    float vh = dot3(wi, h);
+    float fr = pow5(fmaxx(0.0f, 1.0f - vh)); /* eval_fresnel_schlick, brdf.slang:95-97 */
+    float G = g_smith_ggx_correlated(wo[2], wi[2], a2), D = ggx_ndf(a2, h[2]);
+    float pdf_h = g_smith_ggx1(wo[2], a2) * D * fmaxx(0.0f, dot3(wo, h)) / wo[2]; /* pdf_ggx_vn, :161-165 */
+    float pdf_spec = vh > 0.0f ? pdf_h * (1.0f / (4.0f * vh)) / wi[2] : 0.0f;    /* :278,286 */
+    float spec_scale = G * D / (4.0f * wo[2] * wi[2]);                            /* :302-306 */
+    for (int k = 0; k < 3; k++) {
+        float F = b->f0[k] + (1.0f - b->f0[k]) * fr;
+        value[k] = F * spec_scale + b->da[k] * F_FRAC_1_PI * (1.0f - F);
+    }
+    *pdf_proj = b->p_spec * pdf_spec + (1.0f - b->p_spec) * F_FRAC_1_PI;
+}
+/* sample_vndf (brdf.slang:187-216, Heitz 2018 as in Falcor) -> half vector */
+static void sample_vndf(float alpha, const float wo[3], float u0, float u1, float h[3]) {
+    float Vh[3] = {alpha * wo[0], alpha * wo[1], wo[2]};
+    normalize3(Vh);
+    float T1[3] = {1.0f, 0.0f, 0.0f};
+    if (Vh[2] < 0.9999f) { T1[0] = -Vh[1]; T1[1] = Vh[0]; T1[2] = 0.0f; normalize3(T1); } /* cross((0,0,1), Vh) */
+    float T2[3]; cross3(Vh, T1, T2);
+    float r = sqrtf(u0), sp, cp;
+    orc_sincos_2pi(u1, &sp, &cp);
+    float t1 = r * cp, t2 = r * sp, sv = 0.5f * (1.0f + Vh[2]);
+    t2 = (1.0f - sv) * sqrtf(1.0f - t1 * t1) + sv * t2;
+    float nz = sqrtf(fmaxx(0.0f, 1.0f - t1 * t1 - t2 * t2));
+    float Nh[3];
+    for (int k = 0; k < 3; k++) Nh[k] = t1 * T1[k] + t2 * T2[k] + nz * Vh[k];
+    h[0] = alpha * Nh[0]; h[1] = alpha * Nh[1]; h[2] = fmaxx(0.0f, Nh[2]);
+    normalize3(h);
+}
+/* returns 0 if the sample is invalid (path ends); else wi, value_over_pdf (throughput factor) and the solid-angle pdf */
+static int bsdf_sample(const bsdf_t *b, const float wo[3], float u0, float u1, float u2, float wi[3], float vop[3], float *pdf_solid) {
+    if (wo[2] > 1e-5f && u2 < b->p_spec) {
+        float h[3];
+        sample_vndf(b->alpha, wo, u0, u1, h);
+        float s2 = 2.0f * dot3(wo, h);
+        for (int k = 0; k < 3; k++) wi[k] = s2 * h[k] - wo[k]; /* reflect(-wo, m) */
+        if (h[2] <= 1e-5f || wi[2] <= 1e-5f) return 0;        /* BRDF_SAMPLING_MIN_COS, brdf.slang:227 */
+    } else {
+        orc_diffuse_sample(u0, u1, wi);
+    }
+    float value[3], pdf;
+    bsdf_eval(b, wo, wi, value, &pdf);
+    if (!(pdf > 0.0f)) return 0;
+    for (int k = 0; k < 3; k++) vop[k] = value[k] / pdf;
+    *pdf_solid = pdf * wi[2];
+    return 1;
+}
+
 /* ------------------------------------------------------------------------------------------------ passes */
 typedef struct {
     const orc_scene *s; const orc_gconst *g; uint32_t x0, y0, x1, y1;
@@ -1087,7 +1177,7 @@ static void refmode_body(void *c, uint32_t bgn, uint32_t end, int tid) {
     uint32_t W = (uint32_t)g->window_size[0], rw = j->x1 - j->x0;
     const uint32_t flags = g->pad[0], B = g->bounces, S = g->samples;
     const uint32_t dims = flags ? 8u : 2u;
-    const int nee = (flags & ORC_F_NEE_SKY) && s->sky, bnz = (flags & ORC_F_BLUENOISE) && s->bn;
+    const int nee = (flags & ORC_F_NEE_SKY) && s->sky, bnz = (flags & ORC_F_BLUENOISE) && s->bn, spec = (flags & ORC_F_SPECULAR) != 0;
     uint64_t n_ext = 0, n_sh = 0, n_nodes = 0, n_tris = 0;
     for (uint32_t i = bgn; i < end; i++) {
         uint32_t px = j->x0 + i % rw, py = j->y0 + i / rw;
@@ -1124,9 +1214,21 @@ static void refmode_body(void *c, uint32_t bgn, uint32_t end, int tid) {
                 if (bnz) { u0 = bn_shift(u0, bn[0]); u1 = bn_shift(u1, bn[1]); }
                 float *alb = surf, *emi = surf + 3, N[3] = {surf[6], surf[7], surf[8]};
                 if ((flags & ORC_F_FACEFORWARD) && dot3(N, d) > 0.0f) { N[0] = -N[0]; N[1] = -N[1]; N[2] = -N[2]; }
-                float b1[3], b2[3], wi[3];
+                float b1[3], b2[3], wi[3], vop[3] = {alb[0], alb[1], alb[2]}, pdf_s = 0.0f, wo[3] = {0.0f, 0.0f, 1.0f};
+                int valid = 1;
+                bsdf_t bs;
                 orc_onb(N, b1, b2);          /* :44 */
-                orc_diffuse_sample(u0, u1, wi); /* :45 */
+                if (spec) {
+                    bsdf_setup(surf, &bs);
+                    wo[0] = -(d[0] * b1[0] + d[1] * b1[1] + d[2] * b1[2]);
+                    wo[1] = -(d[0] * b2[0] + d[1] * b2[1] + d[2] * b2[2]);
+                    wo[2] = -(d[0] * N[0] + d[1] * N[1] + d[2] * N[2]);
+                    float u2 = orc_uniform_float(seed, base + 2);
+                    valid = bsdf_sample(&bs, wo, u0, u1, u2, wi, vop, &pdf_s);
+                } else {
+                    orc_diffuse_sample(u0, u1, wi); /* :45 */
+                    pdf_s = wi[2] * F_FRAC_1_PI;
+                }
                 for (int k = 0; k < 3; k++) o[k] = o[k] + t * d[k]; /* :47 */
                 for (int k = 0; k < 3; k++) L[k] += T[k] * emi[k]; /* :50 */
                 if (nee) { /* [north_star] next-event estimation against the sky */
@@ -1136,19 +1238,29 @@ static void refmode_body(void *c, uint32_t bgn, uint32_t end, int tid) {
                     sky_sample(s, ul0, ul1, wl, rad, &pl);
                     float cosl = dot3(N, wl);
                     if (cosl > 0.0f && pl > 0.0f) {
-                        float pb = cosl * F_FRAC_1_PI;
-                        float scale = (b == B - 1) ? (cosl * F_FRAC_1_PI) / pl : (cosl * F_FRAC_1_PI) / (pl + pb);
+                        float fv[3], scale;
+                        if (spec) { /* evaluate the layered BSDF towards the light; f cos / (p_light + p_bsdf) */
+                            float wlt[3] = {dot3(wl, b1), dot3(wl, b2), cosl}, pproj;
+                            bsdf_eval(&bs, wo, wlt, fv, &pproj);
+                            float pb = pproj * cosl;
+                            scale = (b == B - 1) ? cosl / pl : cosl / (pl + pb);
+                        } else { /* diffuse: f = albedo / pi folded into the scale */
+                            float pb = cosl * F_FRAC_1_PI;
+                            fv[0] = alb[0]; fv[1] = alb[1]; fv[2] = alb[2];
+                            scale = (b == B - 1) ? (cosl * F_FRAC_1_PI) / pl : (cosl * F_FRAC_1_PI) / (pl + pb);
+                        }
                         hit_t sh;
                         uint32_t cn, ct;
                         traverse(s, o, wl, 0.001f, ORC_BACKGROUND_DEPTH, 1, &sh, &cn, &ct);
                         n_sh++; n_nodes += cn; n_tris += ct;
-                        if (sh.prim == ORC_MISS) for (int k = 0; k < 3; k++) L[k] += (T[k] * alb[k]) * (rad[k] * scale);
+                        if (sh.prim == ORC_MISS) for (int k = 0; k < 3; k++) L[k] += (T[k] * fv[k]) * (rad[k] * scale);
                     }
                 }
+                if (!valid) break; /* invalid specular sample (brdf.slang:227-229): the path ends */
                 float nd[3];
                 onb_apply(b1, b2, N, wi, nd); /* :48 */
-                pdf_b = wi[2] * F_FRAC_1_PI;
-                for (int k = 0; k < 3; k++) { T[k] = T[k] * alb[k]; d[k] = nd[k]; } /* :51 value_over_pdf = albedo */
+                pdf_b = pdf_s;
+                for (int k = 0; k < 3; k++) { T[k] = T[k] * vop[k]; d[k] = nd[k]; } /* :51 value_over_pdf (= albedo for the diffuse BRDF) */
                 if (b != B - 1) { /* :53-56 */
                     hit_t h; uint32_t cn, ct;
                     traverse(s, o, d, 0.001f, ORC_BACKGROUND_DEPTH, 0, &h, &cn, &ct); /* TMin 0.001 (:31) */

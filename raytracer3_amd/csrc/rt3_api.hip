@@ -19,7 +19,7 @@ using namespace rt3;
 
 static_assert(sizeof(rt3_gconst) == 304 && sizeof(GConstDev) == 304, "GConst is 304 bytes (renderer/mod.rs:47-63)");
 static_assert(sizeof(rt3_geometry_info) == 64, "geometry info is 64 bytes");
-static_assert(RT3_F_NEE_SKY == RT3_FLAG_NEE_SKY && RT3_F_BLUENOISE == RT3_FLAG_BLUENOISE && RT3_F_FACEFORWARD == RT3_FLAG_FACEFORWARD, "flags");
+static_assert(RT3_F_NEE_SKY == RT3_FLAG_NEE_SKY && RT3_F_BLUENOISE == RT3_FLAG_BLUENOISE && RT3_F_FACEFORWARD == RT3_FLAG_FACEFORWARD && RT3_F_SPECULAR == RT3_FLAG_SPECULAR, "flags");
 
 namespace {
 
@@ -357,7 +357,6 @@ int pass_reference_mode(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y,
     Resource* li = image_checked(c, b[2], W, H, RT3_FORMAT_R32G32B32A32_SFLOAT, "Light");
     Resource* pv = image_checked(c, b[3], W, H, RT3_FORMAT_R32G32B32A32_SFLOAT, "PrevLight");
     if (!gb || !dp || !li || !pv) return RT3_E_INVALID;
-    if (g->pad[0] & RT3_F_SPECULAR) return fail(c, RT3_E_UNSUPPORTED, "RT3_F_SPECULAR is not implemented in this round");
     const uint32_t Sspp = g->samples, B = g->bounces;
     if (Sspp == 0 || B == 0) return RT3_OK;  // GConst::default() leaves samples = bounces = 0 (renderer/mod.rs:47-63): nothing to trace
     if (B > 64) return fail(c, RT3_E_INVALID, "bounces > 64");

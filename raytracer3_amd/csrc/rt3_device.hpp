@@ -213,6 +213,99 @@ RT3_DEV V3 diffuse_sample(float u0, float u1) {
     return v3(cp * sin_theta, sp * sin_theta, cos_theta);
 }
 
+// ------------------------------------------------------------------------------------------------ layered BSDF
+// DiffuseBrdf (brdf.slang:52-93) under a GGX SpecularBrdf (brdf.slang:141-311: VNDF sampling, height-correlated Smith,
+// Schlick with f90 = 1).  f0 = lerp(0.04, albedo, metalness); diffuse albedo = albedo (1 - metalness), attenuated by the
+// transmitted fraction (1 - F).  One lobe is picked with probability p_spec and the sample is weighted by f / pdf of the
+// mixture.  pdfs are with respect to PROJECTED solid angle (brdf.slang:31); directions live in the tangent frame.
+struct Bsdf {
+    V3 da, f0;
+    float alpha, p_spec;
+};
+RT3_DEV float luminance(V3 c) { return c.x * 0.299f + c.y * 0.587f + c.z * 0.114f; }  // math.slang:119-122
+RT3_DEV float pow5(float x) {
+    float x2 = x * x;
+    return x2 * x2 * x;
+}
+RT3_DEV float g_smith_ggx1(float ndotv, float a2) {  // brdf.slang:111-114
+    float tan2_v = (1.0f - ndotv * ndotv) / (ndotv * ndotv);
+    return 2.0f / (1.0f + sqrtf(1.0f + a2 * tan2_v));
+}
+RT3_DEV float g_smith_ggx_correlated(float ndotv, float ndotl, float a2) {  // brdf.slang:104-109
+    float lambda_v = ndotl * sqrtf((-ndotv * a2 + ndotv) * ndotv + a2);
+    float lambda_l = ndotv * sqrtf((-ndotl * a2 + ndotl) * ndotl + a2);
+    return 2.0f * ndotl * ndotv / (lambda_v + lambda_l);
+}
+RT3_DEV float ggx_ndf(float a2, float cos_theta) {  // brdf.slang:146-149
+    float denom_sqrt = cos_theta * cos_theta * (a2 - 1.0f) + 1.0f;
+    return a2 / (kPi * denom_sqrt * denom_sqrt);
+}
+RT3_DEV Bsdf bsdf_setup(V3 albedo, float roughness, float metalness) {
+    Bsdf b;
+    b.f0 = v3(0.04f + (albedo.x - 0.04f) * metalness, 0.04f + (albedo.y - 0.04f) * metalness, 0.04f + (albedo.z - 0.04f) * metalness);
+    b.da = v3(albedo.x * (1.0f - metalness), albedo.y * (1.0f - metalness), albedo.z * (1.0f - metalness));
+    b.alpha = fmax_sel(roughness, 0.05f);
+    float ls = luminance(b.f0), ld = luminance(b.da);
+    float p = (ls + ld) > 0.0f ? ls / (ls + ld) : 1.0f;
+    b.p_spec = ld > 0.0f ? fmin_sel(fmax_sel(p, 0.1f), 0.9f) : 1.0f;
+    return b;
+}
+// BRDF value (without the cosine) and mixture pdf (projected solid angle)
+RT3_DEV void bsdf_eval(const Bsdf& b, V3 wo, V3 wi, V3& value, float& pdf_proj) {
+    value = v3(0.0f, 0.0f, 0.0f);
+    pdf_proj = 0.0f;
+    if (!(wi.z > 0.0f)) return;
+    if (!(wo.z > 1e-5f)) {  // grazing / back-facing view: diffuse only
+        value = v3(b.da.x * kInvPi, b.da.y * kInvPi, b.da.z * kInvPi);
+        pdf_proj = kInvPi;
+        return;
+    }
+    const float a2 = b.alpha * b.alpha;
+    V3 h = normalize(v3(wo.x + wi.x, wo.y + wi.y, wo.z + wi.z));  // brdf.slang:268
+    float vh = dot(wi, h);
+    float fr = pow5(fmax_sel(0.0f, 1.0f - vh));  // eval_fresnel_schlick, brdf.slang:95-97
+    float G = g_smith_ggx_correlated(wo.z, wi.z, a2), D = ggx_ndf(a2, h.z);
+    float pdf_h = g_smith_ggx1(wo.z, a2) * D * fmax_sel(0.0f, dot(wo, h)) / wo.z;  // pdf_ggx_vn, :161-165
+    float pdf_spec = vh > 0.0f ? pdf_h * (1.0f / (4.0f * vh)) / wi.z : 0.0f;      // :278,286
+    float spec_scale = G * D / (4.0f * wo.z * wi.z);                               // :302-306
+    float Fx = b.f0.x + (1.0f - b.f0.x) * fr, Fy = b.f0.y + (1.0f - b.f0.y) * fr, Fz = b.f0.z + (1.0f - b.f0.z) * fr;
+    value = v3(Fx * spec_scale + b.da.x * kInvPi * (1.0f - Fx), Fy * spec_scale + b.da.y * kInvPi * (1.0f - Fy),
+               Fz * spec_scale + b.da.z * kInvPi * (1.0f - Fz));
+    pdf_proj = b.p_spec * pdf_spec + (1.0f - b.p_spec) * kInvPi;
+}
+// sample_vndf (brdf.slang:187-216) -> half vector
+RT3_DEV V3 sample_vndf(float alpha, V3 wo, float u0, float u1) {
+    V3 Vh = normalize(v3(alpha * wo.x, alpha * wo.y, wo.z));
+    V3 T1 = v3(1.0f, 0.0f, 0.0f);
+    if (Vh.z < 0.9999f) T1 = normalize(v3(-Vh.y, Vh.x, 0.0f));  // cross((0,0,1), Vh)
+    V3 T2 = cross(Vh, T1);
+    float r = sqrtf(u0), sp, cp;
+    sincos_2pi(u1, sp, cp);
+    float t1 = r * cp, t2 = r * sp, sv = 0.5f * (1.0f + Vh.z);
+    t2 = (1.0f - sv) * sqrtf(1.0f - t1 * t1) + sv * t2;
+    float nz = sqrtf(fmax_sel(0.0f, 1.0f - t1 * t1 - t2 * t2));
+    V3 Nh = v3(t1 * T1.x + t2 * T2.x + nz * Vh.x, t1 * T1.y + t2 * T2.y + nz * Vh.y, t1 * T1.z + t2 * T2.z + nz * Vh.z);
+    return normalize(v3(alpha * Nh.x, alpha * Nh.y, fmax_sel(0.0f, Nh.z)));
+}
+// false if the sample is invalid (the path ends); else wi, value_over_pdf and the solid-angle pdf
+RT3_DEV bool bsdf_sample(const Bsdf& b, V3 wo, float u0, float u1, float u2, V3& wi, V3& vop, float& pdf_solid) {
+    if (wo.z > 1e-5f && u2 < b.p_spec) {
+        V3 h = sample_vndf(b.alpha, wo, u0, u1);
+        float s2 = 2.0f * dot(wo, h);
+        wi = v3(s2 * h.x - wo.x, s2 * h.y - wo.y, s2 * h.z - wo.z);  // reflect(-wo, m)
+        if (h.z <= 1e-5f || wi.z <= 1e-5f) return false;               // BRDF_SAMPLING_MIN_COS, brdf.slang:227
+    } else {
+        wi = diffuse_sample(u0, u1);
+    }
+    V3 value;
+    float pdf;
+    bsdf_eval(b, wo, wi, value, pdf);
+    if (!(pdf > 0.0f)) return false;
+    vop = v3(value.x / pdf, value.y / pdf, value.z / pdf);
+    pdf_solid = pdf * wi.z;
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------ camera / primary ray
 struct GConstDev {  // == rt3_gconst (renderer/mod.rs:47-63)
     float proj[16], view[16], proj_inverse[16], view_inverse[16];

@@ -450,6 +450,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
     const uint32_t dims = flags ? 8u : 2u;
     const bool nee = (flags & RT3_FLAG_NEE_SKY) && a.sc.sky != nullptr;
     const bool bnz = (flags & RT3_FLAG_BLUENOISE) && a.sc.bluenoise != nullptr;
+    const bool spec = (flags & RT3_FLAG_SPECULAR) != 0u;
     const size_t S = a.stride;
     const uint32_t n = FIRST ? a.n_first : *a.in_count;
     const uint32_t n_round = (n + (kShadeBlock - 1)) & ~(uint32_t)(kShadeBlock - 1);  // whole workgroups iterate: barriers inside
@@ -526,7 +527,19 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
             if ((flags & RT3_FLAG_FACEFORWARD) && dot(N, d) > 0.0f) N = neg(N);
             V3 b1, b2;
             build_orthonormal_basis(N, b1, b2);  // :44
-            V3 wi = diffuse_sample(u0, u1);      // :45
+            V3 wi, vop = surf.albedo, wo = v3(0.0f, 0.0f, 1.0f);
+            float pdf_s;
+            bool valid = true;
+            Bsdf bs;
+            if (spec) {  // layered diffuse + GGX (brdf.slang:141-311)
+                bs = bsdf_setup(surf.albedo, surf.roughness, surf.metalness);
+                wo = v3(-(d.x * b1.x + d.y * b1.y + d.z * b1.z), -(d.x * b2.x + d.y * b2.y + d.z * b2.z), -(d.x * N.x + d.y * N.y + d.z * N.z));
+                float u2 = uniform_float(seed, base + 2);
+                valid = bsdf_sample(bs, wo, u0, u1, u2, wi, vop, pdf_s);
+            } else {
+                wi = diffuse_sample(u0, u1);  // :45
+                pdf_s = wi.z * kInvPi;
+            }
             o = v3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);  // :47
             // :50 radiance += ray_color * emissive.  x + (+0) == x exactly, so non-emitters skip the read-modify-write.
             if (FIRST) {  // L starts at 0 and T = 1: 0 + 1 * e == e
@@ -549,17 +562,28 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
                 sky_sample(a.sc, ul0, ul1, wl, rad, pl);
                 float cosl = dot(N, wl);
                 if (cosl > 0.0f && pl > 0.0f) {
-                    float pb = cosl * kInvPi;
-                    float scale = (b == B - 1) ? (cosl * kInvPi) / pl : (cosl * kInvPi) / (pl + pb);
-                    contrib = v3((T.x * surf.albedo.x) * (rad.x * scale), (T.y * surf.albedo.y) * (rad.y * scale),
-                                 (T.z * surf.albedo.z) * (rad.z * scale));
+                    V3 fv;
+                    float scale;
+                    if (spec) {  // evaluate the layered BSDF towards the light; f cos / (p_light + p_bsdf)
+                        float pproj;
+                        bsdf_eval(bs, wo, v3(dot(wl, b1), dot(wl, b2), cosl), fv, pproj);
+                        float pb = pproj * cosl;
+                        scale = (b == B - 1) ? cosl / pl : cosl / (pl + pb);
+                    } else {  // diffuse: f = albedo / pi folded into the scale
+                        float pb = cosl * kInvPi;
+                        fv = surf.albedo;
+                        scale = (b == B - 1) ? (cosl * kInvPi) / pl : (cosl * kInvPi) / (pl + pb);
+                    }
+                    contrib = v3((T.x * fv.x) * (rad.x * scale), (T.y * fv.y) * (rad.y * scale), (T.z * fv.z) * (rad.z * scale));
                     emit_shadow = true;
                 }
             }
-            nd = basis_apply(b1, b2, N, wi);  // :48
-            pdf_n = wi.z * kInvPi;
-            Tn = T * surf.albedo;             // :51
-            emit_ext = b != B - 1;            // :53
+            if (valid) {  // an invalid specular sample (brdf.slang:227-229) ends the path
+                nd = basis_apply(b1, b2, N, wi);  // :48
+                pdf_n = pdf_s;
+                Tn = T * vop;                     // :51 value_over_pdf (= albedo for the diffuse BRDF)
+                emit_ext = b != B - 1;            // :53
+            }
         }
         const BlockAppend slot = block_append2(emit_ext, a.out_count, emit_shadow, a.sh_count, append_lds);
         if (emit_shadow) {

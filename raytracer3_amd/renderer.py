@@ -16,7 +16,7 @@ import numpy as np
 from . import _lib as L
 from .render_graph import IMPORTED, ComputePass, Context, DispatchSize, ImageSize, RayTracingPass, RenderGraph, WorkSize2D
 
-DEFAULT_FLAGS = L.F_NEE_SKY | L.F_BLUENOISE | L.F_FACEFORWARD
+DEFAULT_FLAGS = L.F_NEE_SKY | L.F_BLUENOISE | L.F_FACEFORWARD | L.F_SPECULAR  # the full north_star estimator
 
 
 class Camera:
@@ -126,6 +126,7 @@ class PathTracer:
         lib, h, img = self.ctx.lib, self.ctx.h, self.handles["light"]
 
         def pack(buf):
+            torch.cuda.synchronize()  # torch zero-fills `buf` on ITS stream; librt3 writes it on another one
             self.ctx.check(lib.rt3_image_pack_tiles(h, img, self.rank, self.n_ranks, C.c_void_p(buf.data_ptr())))
             self.ctx.wait()  # librt3 runs on its own stream: the tile buffer must be complete before RCCL reads it
 

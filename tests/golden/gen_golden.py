@@ -85,4 +85,5 @@ if __name__ == "__main__":
     FULL = orc.F_NEE_SKY | orc.F_BLUENOISE | orc.F_FACEFORWARD
     scene_fixture("cornell_ref", scenes.cornell(), None, None, scenes.CORNELL_CAMERA, 64, 64, 4, 4, 0, 2)
     scene_fixture("atrium_full", scenes.atrium(0.2), scenes.sky(64, 32), bn, scenes.ATRIUM_CAMERA, 64, 36, 4, 4, FULL, 5)
+    scene_fixture("atrium_spec", scenes.atrium(0.2), scenes.sky(64, 32), bn, scenes.ATRIUM_CAMERA, 64, 36, 4, 4, FULL | orc.F_SPECULAR, 6)
     function_fixture()

@@ -11,7 +11,7 @@ from raytracer3_amd import _lib as L
 from raytracer3_amd.assets import Mesh
 
 GOLD = Path(__file__).resolve().parent / "golden"
-SCENES = ["cornell_ref", "atrium_full"]
+SCENES = ["cornell_ref", "atrium_full", "atrium_spec"]
 
 
 def load(name):
@@ -19,7 +19,7 @@ def load(name):
     mesh = Mesh(z["vertices"], z["indices"], z["geometries"], z["prim_counts"])
     sky = z["sky"] if z["sky"].size else None
     bn = None
-    if name == "atrium_full":
+    if name.startswith("atrium"):
         from raytracer3_amd import assets
 
         bn = assets.load_bluenoise()

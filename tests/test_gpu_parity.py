@@ -18,6 +18,7 @@ from raytracer3_amd.render_graph import Context
 pytestmark = pytest.mark.gpu
 
 FULL = L.F_NEE_SKY | L.F_BLUENOISE | L.F_FACEFORWARD
+SPEC = FULL | L.F_SPECULAR  # + layered GGX BSDF (brdf.slang:141-311)
 
 
 def as_orc(g: L.GConst) -> orc.GConst:
@@ -167,7 +168,7 @@ def render_both(mesh, sky, bn, osc, W, H, cam_kw, samples, bounces, flags, frame
     return g, light, gb, depth, color, st
 
 
-@pytest.mark.parametrize("flags", [0, FULL])
+@pytest.mark.parametrize("flags", [0, FULL, SPEC, L.F_SPECULAR])
 def test_frame_parity_atrium(small, flags):
     mesh, sky, bn, osc = small
     W, H = 160, 90
@@ -272,6 +273,7 @@ def test_pack_unpack_tiles_roundtrip(small):
         n = pt.ctx.tile_pixel_count(r, 4)
         assert n == len(orc.tile_pixels(W, H, r, 4))
         t = torch.zeros((n, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()  # the zero fill runs on torch's stream, the pack kernel on librt3's
         pt.ctx.check(pt.ctx.lib.rt3_image_pack_tiles(pt.ctx.h, pt.handles["light"], r, 4, C.c_void_p(t.data_ptr())))
         bufs.append(t)
     pt.ctx.wait()
