@@ -3,7 +3,8 @@
 (BASELINE.json configs[4]: accumulation over passes with blendfactor = 1/(pass+1), RMSE-vs-spp curve against the final image).
 
   python tools/render.py --scene atrium --size 960x540 --spp 64 --passes 16 --out gpurun_out/atrium.png --curve gpurun_out/curve.json
-  python tools/render.py --scene cornell --size 960x540 --spp 100 --compare resources/refrence.png   (informational only)
+  python tools/render.py --scene cornell --size 960x540 --spp 100 --compare resources/refrence_480x270.png   (informational only;
+                          a 480x270 copy of the reference tree's resources/refrence.png, a Blender-Cycles Cornell box)
   python tools/render.py --glb resources/sponza_scene.glb --exr resources/skybox2.exr ...               (if the real assets are dropped in)
 """
 import argparse
