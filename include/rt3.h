@@ -28,7 +28,7 @@ extern "C" {
 #define RT3_E_HIP (-2)         /* a HIP runtime call failed (text in rt3_last_error) */
 #define RT3_E_NO_DEVICE (-3)   /* no gfx950 device visible */
 #define RT3_E_STATE (-4)       /* call order (e.g. pass launched before rt3_accel_build) */
-#define RT3_E_UNSUPPORTED (-5) /* e.g. base-colour textures (round 1) */
+#define RT3_E_UNSUPPORTED (-5) /* a feature this build does not implement */
 #define RT3_E_DEPTH (-6)       /* BVH deeper than the traversal stack supports */
 
 #define RT3_INVALID_HANDLE 0xFFFFFFFFu
@@ -72,7 +72,7 @@ typedef struct rt3_gconst {
 /* shaders/include/datatypes.slang:11-19 (52 bytes of fields, padded to 64 for float4 alignment) */
 typedef struct rt3_geometry_info {
     float base_color[4];
-    int32_t base_color_texture_index; /* must be -1 in this round (RT3_E_UNSUPPORTED otherwise) */
+    int32_t base_color_texture_index; /* -1 = none, else an index set with rt3_scene_set_texture (hit_logic.slang:31-33) */
     float metallic_factor;
     uint32_t index_offset;
     uint32_t vertex_offset;
@@ -122,6 +122,9 @@ int rt3_scene_set_indices(rt3_ctx *ctx, const uint32_t *indices, uint32_t n_indi
 int rt3_scene_set_geometry(rt3_ctx *ctx, const rt3_geometry_info *infos, const uint32_t *prim_counts, uint32_t n);
 int rt3_scene_set_sky(rt3_ctx *ctx, const float *rgb, uint32_t width, uint32_t height);     /* main.rs:94 (commented skybox2.exr) */
 int rt3_scene_set_bluenoise(rt3_ctx *ctx, const uint8_t *rgba, uint32_t width, uint32_t height); /* resources/bluenoise.png */
+/* base-colour texture `index` (dense indices 0..n-1): RGBA8 with sRGB-encoded colour, sampled bilinearly with repeat
+ * addressing at mip 0 like Textures[i].SampleLevel(uvs, 0.0) (hit_logic.slang:31-33; bindless set 2, bindless/mod.rs:38-77) */
+int rt3_scene_set_texture(rt3_ctx *ctx, uint32_t index, const uint8_t *rgba_srgb, uint32_t width, uint32_t height);
 
 /* ---- acceleration structure: create_acceleration_structure (vulkan/raytracing.rs:88-148) -> GPU LBVH.
  *      Returns the handle (tag 3) in *out_handle, like the TLAS registered at bindless/mod.rs:314-337 ---- */

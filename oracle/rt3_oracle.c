@@ -412,6 +412,9 @@ struct orc_scene {
     float *cdf_cond, *cdf_marg, *pdf_uv;
     /* blue noise */
     uint8_t *bn; uint32_t bn_w, bn_h;
+    /* base-colour textures (RGBA8, sRGB-encoded colour), hit_logic.slang:31-33 */
+    uint8_t **tex; uint32_t *tex_w, *tex_h; uint32_t n_tex;
+    float srgb_lut[256];
 };
 
 orc_scene *orc_scene_create(void) {
@@ -419,6 +422,10 @@ orc_scene *orc_scene_create(void) {
     s->leaf_max = 2;
     s->node_width = 4;
     s->node_quant = 1;
+    for (int i = 0; i < 256; i++) { /* sRGB EOTF, IEC 61966-2-1, in double */
+        double c = i / 255.0;
+        s->srgb_lut[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
+    }
     return s;
 }
 /* leaf_max: 1..8 triangles per leaf; node_width: 2 (64 B nodes) or 4 (128 B nodes).  Call before orc_accel_build. */
@@ -490,6 +497,8 @@ void orc_scene_destroy(orc_scene *s) {
     accel_free(s);
     free(s->verts); free(s->indices); free(s->geoms); free(s->prim_counts); free(s->first_prim); free(s->prim_geom);
     free(s->sky); free(s->cdf_cond); free(s->cdf_marg); free(s->pdf_uv); free(s->bn);
+    for (uint32_t i = 0; i < s->n_tex; i++) free(s->tex[i]);
+    free(s->tex); free(s->tex_w); free(s->tex_h);
     free(s);
 }
 int orc_scene_set_vertices(orc_scene *s, const float *pnt, uint32_t n) {
@@ -526,6 +535,38 @@ int orc_scene_set_bluenoise(orc_scene *s, const uint8_t *rgba, uint32_t w, uint3
     memcpy(s->bn, rgba, (size_t)w * h * 4);
     s->bn_w = w; s->bn_h = h;
     return 0;
+}
+/* texture `index` = RGBA8 image with sRGB-encoded colour (what a glTF baseColorTexture is); indices must be set 0,1,2,... */
+int orc_scene_set_texture(orc_scene *s, uint32_t index, const uint8_t *rgba, uint32_t w, uint32_t h) {
+    if (index > s->n_tex || !w || !h) return -1;
+    if (index == s->n_tex) {
+        s->tex = (uint8_t **)realloc(s->tex, (size_t)(index + 1) * sizeof(uint8_t *));
+        s->tex_w = (uint32_t *)realloc(s->tex_w, (size_t)(index + 1) * 4);
+        s->tex_h = (uint32_t *)realloc(s->tex_h, (size_t)(index + 1) * 4);
+        s->tex[index] = NULL;
+        s->n_tex = index + 1;
+    }
+    free(s->tex[index]);
+    s->tex[index] = (uint8_t *)malloc((size_t)w * h * 4);
+    memcpy(s->tex[index], rgba, (size_t)w * h * 4);
+    s->tex_w[index] = w; s->tex_h[index] = h;
+    return 0;
+}
+/* Textures[i].SampleLevel(uv, 0).xyz (hit_logic.slang:32): sRGB decode per texel, bilinear, repeat addressing, mip 0 */
+static void texture_sample(const orc_scene *s, uint32_t index, float u, float v, float out[3]) {
+    int W = (int)s->tex_w[index], H = (int)s->tex_h[index];
+    const uint8_t *px = s->tex[index];
+    float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    float xf = floorf(x), yf = floorf(y), fx = x - xf, fy = y - yf;
+    int x0 = (int)xf, y0 = (int)yf, x1 = x0 + 1, y1 = y0 + 1;
+    x0 = ((x0 % W) + W) % W; x1 = ((x1 % W) + W) % W; y0 = ((y0 % H) + H) % H; y1 = ((y1 % H) + H) % H;
+    const uint8_t *p00 = px + 4 * ((size_t)y0 * W + x0), *p10 = px + 4 * ((size_t)y0 * W + x1);
+    const uint8_t *p01 = px + 4 * ((size_t)y1 * W + x0), *p11 = px + 4 * ((size_t)y1 * W + x1);
+    for (int k = 0; k < 3; k++) {
+        float top = s->srgb_lut[p00[k]] * (1.0f - fx) + s->srgb_lut[p10[k]] * fx;
+        float bot = s->srgb_lut[p01[k]] * (1.0f - fx) + s->srgb_lut[p11[k]] * fx;
+        out[k] = top * (1.0f - fy) + bot * fy;
+    }
 }
 /* math.slang:119-122 */
 static float luminance3(const float c[3]) { return c[0] * 0.299f + c[1] * 0.587f + c[2] * 0.114f; }
@@ -956,7 +997,7 @@ void orc_trace_brute(const orc_scene *s, const float *rays, uint32_t n, float *t
 }
 
 /* ------------------------------------------------------------------------------------------------ hit_info */
-/* hit_logic.slang:5-40 with GeometryInfo.transform := identity, Vertex.color := 1, no textures (index -1);
+/* hit_logic.slang:5-40 with GeometryInfo.transform := identity, Vertex.color := 1;
  * surf = albedo[3] emissive[3] normal[3] roughness metalness */
 void orc_hit_info(const orc_scene *s, uint32_t prim, float bu, float bv, float surf[11]) {
     uint32_t g = s->prim_geom[prim], local = prim - s->first_prim[g];
@@ -971,6 +1012,11 @@ void orc_hit_info(const orc_scene *s, uint32_t prim, float bu, float bv, float s
     normalize3(n); /* :24 */
     normalize3(n); /* :25 (identity transform, second normalize kept) */
     surf[0] = gi->base_color[0]; surf[1] = gi->base_color[1]; surf[2] = gi->base_color[2];
+    if (gi->base_color_texture_index > -1 && (uint32_t)gi->base_color_texture_index < s->n_tex) { /* :27,31-33 */
+        float uu = v0[6] * b0 + v1[6] * b1 + v2[6] * b2, vv = v0[7] * b0 + v1[7] * b1 + v2[7] * b2, tc[3];
+        texture_sample(s, (uint32_t)gi->base_color_texture_index, uu, vv, tc);
+        surf[0] = surf[0] * tc[0]; surf[1] = surf[1] * tc[1]; surf[2] = surf[2] * tc[2];
+    }
     surf[3] = gi->emission[0] * 12.0f; surf[4] = gi->emission[1] * 12.0f; surf[5] = gi->emission[2] * 12.0f; /* :36 */
     surf[6] = n[0]; surf[7] = n[1]; surf[8] = n[2];
     surf[9] = gi->roughness; surf[10] = gi->metallic_factor;

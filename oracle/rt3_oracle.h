@@ -101,6 +101,7 @@ int orc_scene_set_indices(orc_scene *s, const uint32_t *idx, uint32_t n_indices)
 int orc_scene_set_geometry(orc_scene *s, const orc_geometry_info *g, const uint32_t *prim_counts, uint32_t n);
 int orc_scene_set_sky(orc_scene *s, const float *rgb, uint32_t w, uint32_t h);
 int orc_scene_set_bluenoise(orc_scene *s, const uint8_t *rgba, uint32_t w, uint32_t h);
+int orc_scene_set_texture(orc_scene *s, uint32_t index, const uint8_t *rgba_srgb, uint32_t w, uint32_t h); /* hit_logic.slang:31-33 */
 /* LBVH (Karras 2012) over all triangles; replaces raytracing.rs:88-148 */
 /* leaf_max 1..8 triangles per leaf (default 2); node_width 2 = 64 B binary nodes, 4 = four-wide nodes (default);
  * quantized (width 4 only): 64 B nodes with 8-bit conservative child boxes instead of 128 B fp32 boxes */

@@ -19,7 +19,7 @@ OPT_BATCH_SPP, OPT_PROFILE, OPT_COUNT_TRAVERSAL, OPT_EXTEND_VARIANT, OPT_LEAF_SI
 
 EXPORTS = [
     "rt3_create", "rt3_destroy", "rt3_last_error", "rt3_device_name", "rt3_set_option",
-    "rt3_scene_set_vertices", "rt3_scene_set_indices", "rt3_scene_set_geometry", "rt3_scene_set_sky", "rt3_scene_set_bluenoise",
+    "rt3_scene_set_vertices", "rt3_scene_set_indices", "rt3_scene_set_geometry", "rt3_scene_set_sky", "rt3_scene_set_bluenoise", "rt3_scene_set_texture",
     "rt3_accel_build", "rt3_accel_info", "rt3_accel_download", "rt3_sky_download",
     "rt3_buffer_create", "rt3_image_create", "rt3_image_import", "rt3_resource_upload", "rt3_resource_download", "rt3_resource_device_ptr",
     "rt3_set_tile_partition", "rt3_tile_pixel_count", "rt3_image_pack_tiles", "rt3_image_unpack_tiles",
@@ -82,6 +82,7 @@ def load():
         "rt3_scene_set_geometry": (i32, [vp, vp, vp, u32]),
         "rt3_scene_set_sky": (i32, [vp, vp, u32, u32]),
         "rt3_scene_set_bluenoise": (i32, [vp, vp, u32, u32]),
+        "rt3_scene_set_texture": (i32, [vp, u32, vp, u32, u32]),
         "rt3_accel_build": (i32, [vp, pu32]),
         "rt3_accel_info": (i32, [vp, pu32, pu32, pu32, pu32]),
         "rt3_accel_download": (i32, [vp, vp, sz, vp, sz]),

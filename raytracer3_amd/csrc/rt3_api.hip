@@ -65,9 +65,17 @@ struct rt3_ctx {
     uint32_t sky_w = 0, sky_h = 0;
     uint8_t* d_bn = nullptr;
     uint32_t bn_w = 0, bn_h = 0;
+    // base-colour textures: host staging (RGBA8) + device atlas rebuilt lazily
+    std::vector<std::vector<uint8_t>> h_tex;
+    std::vector<uint32_t> tex_w, tex_h;
+    uint8_t* d_tex_pixels = nullptr;
+    uint4* d_tex_table = nullptr;
+    float* d_srgb_lut = nullptr;
+    bool tex_dirty = false;
     LbvhResult bvh;
     bool accel_built = false;
     std::vector<uint32_t> h_indices;  // host copy, only for range validation in rt3_scene_set_geometry
+    int64_t max_tex_index = -1;
     // resources
     std::vector<Resource> resources;
     std::vector<PixelList> pixlists;
@@ -197,7 +205,41 @@ SceneDev scene_dev(const rt3_ctx* c) {
     s.bluenoise = c->d_bn;
     s.bn_w = c->bn_w;
     s.bn_h = c->bn_h;
+    s.tex_pixels = c->d_tex_pixels;
+    s.tex_table = c->d_tex_table;
+    s.srgb_lut = c->d_srgb_lut;
+    s.n_tex = c->d_tex_pixels ? (uint32_t)c->h_tex.size() : 0u;
     return s;
+}
+
+// (re)build the device texture atlas after rt3_scene_set_texture calls
+int sync_textures(rt3_ctx* c) {
+    if (!c->tex_dirty) return RT3_OK;
+    std::vector<uint4> table(c->h_tex.size());
+    size_t total = 0;
+    for (size_t i = 0; i < c->h_tex.size(); i++) {
+        if (c->h_tex[i].empty()) return fail(c, RT3_E_STATE, "texture " + std::to_string(i) + " was never set (indices must be dense)");
+        table[i] = make_uint4((uint32_t)total, c->tex_w[i], c->tex_h[i], 0u);
+        total += c->h_tex[i].size();
+    }
+    if (total > 0xFFFFFFF0ull) return fail(c, RT3_E_INVALID, "textures exceed 4 GiB");
+    std::vector<uint8_t> all(total);
+    for (size_t i = 0; i < c->h_tex.size(); i++) memcpy(all.data() + table[i].x, c->h_tex[i].data(), c->h_tex[i].size());
+    if (int r = dev_alloc(c, &c->d_tex_pixels, total)) return r;
+    if (int r = dev_alloc(c, &c->d_tex_table, table.size())) return r;
+    HIPC(c, hipMemcpy(c->d_tex_pixels, all.data(), total, hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(c->d_tex_table, table.data(), table.size() * sizeof(uint4), hipMemcpyHostToDevice));
+    if (!c->d_srgb_lut) {
+        float lut[256];
+        for (int i = 0; i < 256; i++) {  // sRGB EOTF (IEC 61966-2-1), evaluated in double
+            double v = i / 255.0;
+            lut[i] = (float)(v <= 0.04045 ? v / 12.92 : std::pow((v + 0.055) / 1.055, 2.4));
+        }
+        if (int r = dev_alloc(c, &c->d_srgb_lut, (size_t)256)) return r;
+        HIPC(c, hipMemcpy(c->d_srgb_lut, lut, sizeof(lut), hipMemcpyHostToDevice));
+    }
+    c->tex_dirty = false;
+    return RT3_OK;
 }
 
 int ensure_work(rt3_ctx* c, size_t paths, size_t npix) {
@@ -473,6 +515,7 @@ void rt3_destroy(rt3_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dev_free(c->d_verts); dev_free(c->d_indices); dev_free(c->d_geoms); dev_free(c->d_prim_geom); dev_free(c->d_first_prim);
+    dev_free(c->d_tex_pixels); dev_free(c->d_tex_table); dev_free(c->d_srgb_lut);
     dev_free(c->d_sky); dev_free(c->d_cdf_cond); dev_free(c->d_cdf_marg); dev_free(c->d_pdf_uv); dev_free(c->d_bn);
     dev_free(c->bvh.nodes); dev_free(c->bvh.tris); dev_free(c->bvh.tri_shade); dev_free(c->d_guide_cond); dev_free(c->d_guide_marg);
     for (auto& r : c->resources)
@@ -548,8 +591,9 @@ int rt3_scene_set_geometry(rt3_ctx* c, const rt3_geometry_info* g, const uint32_
     HIPC(c, hipSetDevice(c->device));
     std::vector<uint32_t> first(n ? n : 1), pg;
     uint64_t total = 0;
+    int64_t max_tex = -1;
     for (uint32_t i = 0; i < n; i++) {
-        if (g[i].base_color_texture_index > -1) return fail(c, RT3_E_UNSUPPORTED, "base-colour textures are not supported in this round (hit_logic.slang:31-33)");
+        if (g[i].base_color_texture_index > max_tex) max_tex = g[i].base_color_texture_index;
         // bounds: the kernels index the world buffers without checks (a GPU fault would take the node down)
         if ((uint64_t)g[i].index_offset + 3ull * prim_counts[i] > c->n_indices) return fail(c, RT3_E_INVALID, "geometry index range exceeds the index buffer");
         uint32_t mx = 0;
@@ -575,6 +619,7 @@ int rt3_scene_set_geometry(rt3_ctx* c, const rt3_geometry_info* g, const uint32_
     }
     if (total) HIPC(c, hipMemcpy(c->d_prim_geom, pg.data(), (size_t)total * 4, hipMemcpyHostToDevice));
     c->n_geoms = n;
+    c->max_tex_index = max_tex;
     c->n_prims = (uint32_t)total;
     c->accel_built = false;
     return RT3_OK;
@@ -649,6 +694,20 @@ int rt3_scene_set_bluenoise(rt3_ctx* c, const uint8_t* rgba, uint32_t w, uint32_
     HIPC(c, hipMemcpy(c->d_bn, rgba, (size_t)w * h * 4, hipMemcpyHostToDevice));
     c->bn_w = w;
     c->bn_h = h;
+    return RT3_OK;
+}
+// base-colour texture `index` (RGBA8, sRGB-encoded colour), sampled by hit_info when GeometryInfo.baseColorTextureIndex == index
+int rt3_scene_set_texture(rt3_ctx* c, uint32_t index, const uint8_t* rgba, uint32_t w, uint32_t h) {
+    if (!c || !rgba || !w || !h || w > 16384 || h > 16384 || index > 4096) return fail(c, RT3_E_INVALID, "texture: NULL / bad size / index");
+    if (index >= c->h_tex.size()) {
+        c->h_tex.resize(index + 1);
+        c->tex_w.resize(index + 1, 0);
+        c->tex_h.resize(index + 1, 0);
+    }
+    c->h_tex[index].assign(rgba, rgba + (size_t)w * h * 4);
+    c->tex_w[index] = w;
+    c->tex_h[index] = h;
+    c->tex_dirty = true;
     return RT3_OK;
 }
 int rt3_sky_download(rt3_ctx* c, float* cond, float* marg, float* pdf) {
@@ -828,6 +887,10 @@ int rt3_pass_launch(rt3_ctx* c, const char* pass_name, const char* entry, uint32
     if (!bindings && n_bindings) return fail(c, RT3_E_INVALID, "bindings NULL");
     if (!c->accel_built) return fail(c, RT3_E_STATE, "rt3_accel_build has not been called for the current scene");
     HIPC(c, hipSetDevice(c->device));
+    if (int r = sync_textures(c)) return r;
+    if (c->max_tex_index >= (int64_t)c->h_tex.size())
+        return fail(c, RT3_E_STATE, "a geometry references base-colour texture " + std::to_string(c->max_tex_index) + " but only " +
+                                        std::to_string(c->h_tex.size()) + " texture(s) were set (rt3_scene_set_texture)");
     rt3_gconst g;
     memcpy(&g, constants, sizeof(g));
     if (!strcmp(pass_name, "gbuffer")) return pass_gbuffer(c, &g, x, y, bindings, n_bindings);

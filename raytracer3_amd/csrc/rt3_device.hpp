@@ -350,7 +350,11 @@ struct SceneDev {
     const GeometryInfoDev* geoms;
     const uint32_t* prim_geom;   // global primitive -> geometry
     const uint32_t* first_prim;  // geometry -> first global primitive
-    const float4* tri_shade;     // per global primitive, 64 B: {n0.xyz,n1.x} {n1.yz,n2.xy} {n2.z,geometry,-,-} {-}: one cache line
+    const float4* tri_shade;     // per global primitive, 64 B: {n0.xyz,n1.x} {n1.yz,n2.xy} {n2.z,geometry,uv0} {uv1,uv2}: one cache line
+    const uint8_t* tex_pixels;   // all base-colour textures, RGBA8 (sRGB-encoded colour), back to back
+    const uint4* tex_table;      // per texture {byte offset, width, height, -}
+    const float* srgb_lut;       // 256 entries: sRGB EOTF
+    uint32_t n_tex;
     // sky
     const float* sky;            // rgb
     const float* cdf_cond;
@@ -363,8 +367,31 @@ struct SceneDev {
     uint32_t bn_w, bn_h;
 };
 
-// hit_logic.slang:5-40 (transform = identity, vertex colour = 1, no textures).  The three index + three vertex gathers of
+// hit_logic.slang:5-40 (transform = identity, vertex colour = 1).  The three index + three vertex gathers of
 // :10-20 are folded at build time into one 64-byte shading record per primitive (same values, one cache line).
+// Textures[i].SampleLevel(uv, 0).xyz (hit_logic.slang:32): sRGB decode per texel, bilinear, repeat addressing, mip 0
+RT3_DEV V3 texture_sample(const SceneDev& sc, uint32_t index, float u, float v) {
+    const uint4 t = sc.tex_table[index];
+    const int W = (int)t.y, H = (int)t.z;
+    const uint8_t* px = sc.tex_pixels + t.x;
+    float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    float xf = floorf(x), yf = floorf(y), fx = x - xf, fy = y - yf;
+    int x0 = (int)xf, y0 = (int)yf, x1 = x0 + 1, y1 = y0 + 1;
+    x0 = ((x0 % W) + W) % W;
+    x1 = ((x1 % W) + W) % W;
+    y0 = ((y0 % H) + H) % H;
+    y1 = ((y1 % H) + H) % H;
+    const uint32_t p00 = *reinterpret_cast<const uint32_t*>(px + 4 * ((size_t)y0 * W + x0)), p10 = *reinterpret_cast<const uint32_t*>(px + 4 * ((size_t)y0 * W + x1));
+    const uint32_t p01 = *reinterpret_cast<const uint32_t*>(px + 4 * ((size_t)y1 * W + x0)), p11 = *reinterpret_cast<const uint32_t*>(px + 4 * ((size_t)y1 * W + x1));
+    float o[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        float top = sc.srgb_lut[(p00 >> (8 * k)) & 0xFFu] * (1.0f - fx) + sc.srgb_lut[(p10 >> (8 * k)) & 0xFFu] * fx;
+        float bot = sc.srgb_lut[(p01 >> (8 * k)) & 0xFFu] * (1.0f - fx) + sc.srgb_lut[(p11 >> (8 * k)) & 0xFFu] * fx;
+        o[k] = top * (1.0f - fy) + bot * fy;
+    }
+    return v3(o[0], o[1], o[2]);
+}
 RT3_DEV Surface hit_info(const SceneDev& sc, uint32_t prim, float bu, float bv) {
     const float4* rec = sc.tri_shade + 4 * (size_t)prim;
     float4 a = rec[0], b = rec[1], c = rec[2];
@@ -374,6 +401,11 @@ RT3_DEV Surface hit_info(const SceneDev& sc, uint32_t prim, float bu, float bv) 
     n = normalize(normalize(n));  // :24 and :25
     Surface s;
     s.albedo = v3(gi.base_color[0], gi.base_color[1], gi.base_color[2]);
+    if (gi.tex > -1 && (uint32_t)gi.tex < sc.n_tex) {  // :27,31-33
+        float4 e = rec[3];
+        float uu = c.z * b0 + e.x * bu + e.z * bv, vv = c.w * b0 + e.y * bu + e.w * bv;
+        s.albedo = s.albedo * texture_sample(sc, (uint32_t)gi.tex, uu, vv);
+    }
     s.emissive = v3(gi.emission[0] * 12.0f, gi.emission[1] * 12.0f, gi.emission[2] * 12.0f);  // :36
     s.normal = n;
     s.roughness = gi.roughness;

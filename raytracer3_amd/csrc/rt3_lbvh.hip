@@ -82,7 +82,7 @@ __global__ void k_prim_bounds(const float* verts, const uint32_t* indices, const
     }
 }
 
-// shading record of hit_logic.slang:10-25: the three vertex normals + the geometry index of each primitive, 64 B
+// shading record of hit_logic.slang:10-27: the three vertex normals, the geometry index and the three uv pairs, 64 B
 __global__ void k_tri_shade(const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,
                             const uint32_t* first_prim, uint32_t n, float4* rec) {
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
@@ -94,8 +94,8 @@ __global__ void k_tri_shade(const float* verts, const uint32_t* indices, const G
         const float* v2 = verts + 8 * (size_t)(gi.vertex_offset + indices[io + 2]);
         rec[4 * (size_t)p + 0] = make_float4(v0[3], v0[4], v0[5], v1[3]);
         rec[4 * (size_t)p + 1] = make_float4(v1[4], v1[5], v2[3], v2[4]);
-        rec[4 * (size_t)p + 2] = make_float4(v2[5], __uint_as_float(g), 0.0f, 0.0f);
-        rec[4 * (size_t)p + 3] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        rec[4 * (size_t)p + 2] = make_float4(v2[5], __uint_as_float(g), v0[6], v0[7]);
+        rec[4 * (size_t)p + 3] = make_float4(v1[6], v1[7], v2[6], v2[7]);
     }
 }
 

@@ -170,6 +170,9 @@ class Context:
         self.check(self.lib.rt3_scene_set_vertices(self.h, v.ctypes.data, len(v)))
         self.check(self.lib.rt3_scene_set_indices(self.h, i.ctypes.data, len(i)))
         self.check(self.lib.rt3_scene_set_geometry(self.h, g.ctypes.data, pc.ctypes.data, len(g)))
+        for i, t in enumerate(getattr(mesh, "textures", None) or []):  # base-colour textures, RGBA8 sRGB
+            t = np.ascontiguousarray(t, np.uint8)
+            self.check(self.lib.rt3_scene_set_texture(self.h, i, t.ctypes.data, t.shape[1], t.shape[0]))
 
     def set_sky(self, rgb):
         s = np.ascontiguousarray(rgb, np.float32)

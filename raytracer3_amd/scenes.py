@@ -241,6 +241,25 @@ def cornell() -> Mesh:
     return mb.build()
 
 
+def textured_cornell() -> Mesh:
+    """The Cornell box with base-colour textures (hit_logic.slang:31-33): checker floor, gradient back wall."""
+    mesh = cornell()
+    yy, xx = np.mgrid[0:64, 0:64]
+    checker = np.where(((xx // 8) + (yy // 8)) % 2 == 0, 230, 40).astype(np.uint8)
+    t0 = np.stack([checker, checker, (checker // 2 + 60).astype(np.uint8), np.full_like(checker, 255)], -1)
+    yy, xx = np.mgrid[0:32, 0:48]
+    t1 = np.stack([(xx * 5).astype(np.uint8), (yy * 7).astype(np.uint8), np.full(xx.shape, 128, np.uint8), np.full(xx.shape, 255, np.uint8)], -1)
+    mesh.textures = [np.ascontiguousarray(t0), np.ascontiguousarray(t1)]
+    for name, tex in (("floor", 0), ("floor2", 0), ("back", 1)):
+        g = mesh.names.index(name)
+        mesh.geometries["base_color_texture_index"][g] = tex
+        mesh.geometries["base_color"][g] = (1.0, 1.0, 1.0, 1.0)
+        vo = int(mesh.geometries["vertex_offset"][g])
+        later = [int(x) for x in mesh.geometries["vertex_offset"] if int(x) > vo]
+        mesh.vertices[vo : (min(later) if later else len(mesh.vertices)), 6:8] *= 3.0  # repeat addressing: uv up to 3
+    return mesh
+
+
 def sky(width: int = 2048, height: int = 1024, seed: int = SKY_SEED) -> np.ndarray:
     """Equirect RGB32F sky: horizon-to-zenith gradient, ground bounce, soft cloud noise, 0.5 degree sun (5e4)."""
     rng = np.random.default_rng(seed)

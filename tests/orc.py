@@ -51,6 +51,7 @@ def lib():
         L.orc_scene_set_geometry.argtypes = [vp, vp, vp, u32]
         L.orc_scene_set_sky.argtypes = [vp, vp, u32, u32]
         L.orc_scene_set_bluenoise.argtypes = [vp, vp, u32, u32]
+        L.orc_scene_set_texture.argtypes = [vp, u32, vp, u32, u32]
         for n in ("orc_accel_num_tris", "orc_accel_num_nodes", "orc_accel_max_depth"):
             getattr(L, n).restype = u32; getattr(L, n).argtypes = [vp]
         for n in ("orc_accel_nodes", "orc_accel_tris", "orc_accel_codes", "orc_sky_cdf_cond", "orc_sky_cdf_marg", "orc_sky_pdf_uv"):
@@ -99,6 +100,9 @@ class Scene:
         if bluenoise is not None:
             b = np.ascontiguousarray(bluenoise, np.uint8)
             L.orc_scene_set_bluenoise(self.h, ptr(b), b.shape[1], b.shape[0])
+        for i, t in enumerate(getattr(mesh, "textures", None) or []):
+            t = np.ascontiguousarray(t, np.uint8)
+            assert L.orc_scene_set_texture(self.h, i, ptr(t), t.shape[1], t.shape[0]) == 0
         if build:
             L.orc_accel_build(self.h)
 

@@ -210,6 +210,23 @@ def test_frame_parity_cornell_reference_semantics(cornell):
     assert int(counts[0]) >= 0.999 * W * H * 16 * 3
 
 
+def test_frame_parity_textured_cornell():
+    """base-colour textures (hit_logic.slang:31-33): sRGB decode, bilinear, repeat addressing -- bit-exact vs the oracle"""
+    mesh = scenes.textured_cornell()
+    osc = orc.Scene(mesh)
+    W, H = 128, 96
+    g, light, gb, depth, color, st = render_both(mesh, None, None, osc, W, H, scenes.CORNELL_CAMERA, 8, 3, L.F_SPECULAR | L.F_FACEFORWARD, frame=2)
+    og = as_orc(g)
+    ogb, odepth = osc.gbuffer(og)
+    assert np.array_equal(gb, ogb) and np.array_equal(depth, odepth)
+    olight, _ = osc.reference_mode(og, ogb, odepth)
+    assert np.array_equal(light.view(np.uint32), olight.view(np.uint32))
+    # the texture really modulates the albedo: the floor pixels are not uniform any more
+    plain = orc.Scene(scenes.cornell())
+    pgb, _ = plain.gbuffer(og)
+    assert (pgb[..., 0] != ogb[..., 0]).mean() > 0.2
+
+
 def test_batching_and_blend_do_not_change_the_image(small):
     mesh, sky, bn, osc = small
     W, H = 96, 54
@@ -315,11 +332,18 @@ def test_error_behaviour(small):
     assert lib.rt3_image_create(ctx.h, 64, 64, 12345, C.byref(img)) == L.E_INVALID
     assert lib.rt3_image_create(ctx.h, 64, 64, L.FORMAT_R32_SFLOAT, C.byref(img)) == 0
     assert img.value >> 30 == L.TAG_IMAGE
-    # textures are not supported in this round
+    # a geometry that references a texture nobody uploaded is refused at launch time, not dereferenced on the GPU
     gi = mesh.geometries.copy()
     gi["base_color_texture_index"][0] = 0
     pc = np.ascontiguousarray(mesh.prim_counts)
-    assert lib.rt3_scene_set_geometry(ctx.h, gi.ctypes.data, pc.ctypes.data, len(gi)) == L.E_UNSUPPORTED
+    assert lib.rt3_scene_set_geometry(ctx.h, gi.ctypes.data, pc.ctypes.data, len(gi)) == 0
+    out = C.c_uint32()
+    assert lib.rt3_accel_build(ctx.h, C.byref(out)) == 0
+    i0, i1 = C.c_uint32(), C.c_uint32()
+    assert lib.rt3_image_create(ctx.h, 64, 64, L.FORMAT_R32G32B32A32_UINT, C.byref(i0)) == 0 and lib.rt3_image_create(ctx.h, 64, 64, L.FORMAT_R32_SFLOAT, C.byref(i1)) == 0
+    bb = (C.c_uint32 * 2)(i0.value, i1.value)
+    assert lib.rt3_pass_launch(ctx.h, b"gbuffer", b"main", 64, 64, 1, C.byref(g), 304, bb, 2) == L.E_STATE
+    assert b"texture" in lib.rt3_last_error(ctx.h)
     # out-of-range geometry is rejected on the host instead of faulting on the GPU
     gi = mesh.geometries.copy()
     gi["index_offset"][-1] = 2**31

@@ -148,6 +148,16 @@ def test_glb_and_exr_roundtrip(tmp_path):
     assert bn.shape == (256, 256, 4) and abs(bn.mean() - 127.5) < 0.01  # 4 independent uniform channels
 
 
+def test_glb_textures_roundtrip(tmp_path):
+    mesh = scenes.textured_cornell()
+    p = tmp_path / "t.glb"
+    assets.write_glb(p, mesh)
+    back = assets.GltfMeshLoader.load(p)
+    assert len(back.textures) == 2 and all(np.array_equal(a, b) for a, b in zip(back.textures, mesh.textures))
+    assert np.array_equal(back.geometries["base_color_texture_index"], mesh.geometries["base_color_texture_index"])
+    assert np.array_equal(back.vertices, mesh.vertices)
+
+
 def test_glb_node_transforms_are_baked(tmp_path):
     import json, struct
 
