@@ -57,11 +57,18 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dist = None
+    # RT3_DIST_BACKEND=gloo is a REHEARSAL mode for a 1-GPU box: several ranks share GPU 0 and the gather goes through
+    # host tensors.  The real multi-GPU run uses nccl (= RCCL over xGMI), one GPU per rank.
+    backend = os.environ.get("RT3_DIST_BACKEND", "nccl")
+    device_index = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
 
@@ -73,7 +80,8 @@ def main():
     mesh = scenes.atrium(args.detail)
     sky = scenes.sky(2048, 1024)
     bn = assets.load_bluenoise()
-    pt = PathTracer((W, H), device=local_rank, rank=rank, n_ranks=world)
+    pt = PathTracer((W, H), device=device_index if world > 1 else 0, rank=rank, n_ranks=world)
+    pt.host_staged_gather = world > 1 and backend != "nccl"
     if args.leaf_size:
         pt.ctx.set_option(L.OPT_LEAF_SIZE, args.leaf_size)
     if args.node_width:
@@ -113,9 +121,10 @@ def main():
 
     rays_local = st.extension_rays + st.shadow_rays
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        red_dev = "cuda" if backend == "nccl" else "cpu"
+        tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        rr = torch.tensor([float(rays_local), float(st.extension_rays), float(st.shadow_rays)], dtype=torch.float64, device="cuda")
+        rr = torch.tensor([float(rays_local), float(st.extension_rays), float(st.shadow_rays)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
         dt = float(tt.item())
         rays_total, ext_total, sh_total = (float(x) for x in rr.tolist())
@@ -153,7 +162,7 @@ def main():
         "metric": "Mrays/s", "value": round(rays_total / dt / 1e6, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"C3: atrium stand-in ({mesh.n_triangles} tris) {W}x{H}@{args.spp}spp B={args.bounces} diffuse BSDF + sky NEE/MIS + bluenoise, "
+        "config": {"workload": f"C3: atrium stand-in ({mesh.n_triangles} tris) {W}x{H}@{args.spp}spp B={args.bounces} layered BSDF (diffuse + GGX) + sky NEE/MIS + bluenoise, "
                                f"64x64 tiles over {world} GPU(s), one gather", "rays_per_frame": int(rays_total / max(args.steps, 1)),
                    "extension_rays_per_frame": int(ext_total / max(args.steps, 1)), "shadow_rays_per_frame": int(sh_total / max(args.steps, 1)),
                    "device": pt.ctx.device_name},
@@ -192,6 +201,14 @@ def main():
         _, _, _, _, on, ot = osc.trace_closest(pr, threads=threads, counts=True)
         out["roofline"]["counts_match_oracle"] = bool(np.array_equal(gn, on) and np.array_equal(gt, ot))
 
+    if world > 1 and os.environ.get("RT3_CHECK_GATHER"):  # rehearsal aid: the gathered frame must equal a 1-rank render of it
+        full = pt.gather_light(dist, torch)
+        if rank == 0:
+            solo = PathTracer((W, H), device=device_index)
+            solo.set_scene(mesh, sky, bn)
+            solo.render(g_last, postprocess=False, wait=True)
+            out["gather_bit_identical_to_single_rank"] = bool(np.array_equal(full.view(np.uint32), solo.light().view(np.uint32)))
+            solo.close()
     if rank == 0:
         print(json.dumps(out))
     pt.close()

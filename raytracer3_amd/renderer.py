@@ -53,6 +53,7 @@ class PathTracer:
         self.ctx.set_tile_partition(self.window[0], self.window[1], rank, n_ranks)
         self.rg = RenderGraph(self.ctx, self.window)
         self._accel = None
+        self.host_staged_gather = False  # rehearsal only: gather through host tensors (gloo) instead of device tensors (nccl/RCCL)
 
     def close(self):
         self.ctx.close()
@@ -134,7 +135,18 @@ class PathTracer:
             torch.cuda.synchronize()
             self.ctx.check(lib.rt3_image_unpack_tiles(h, img, r, self.n_ranks, C.c_void_p(buf.data_ptr())))
 
-        done = gather_tiles(dist, torch, dev, self.rank, self.n_ranks, counts, pack, unpack, dst)
+        if self.host_staged_gather:
+            def pack_host(buf):
+                g = torch.zeros_like(buf, device=dev)
+                pack(g)
+                buf.copy_(g.cpu())
+
+            def unpack_host(r, buf):
+                unpack(r, buf.to(dev))
+
+            done = gather_tiles(dist, torch, torch.device("cpu"), self.rank, self.n_ranks, counts, pack_host, unpack_host, dst)
+        else:
+            done = gather_tiles(dist, torch, dev, self.rank, self.n_ranks, counts, pack, unpack, dst)
         if not done:
             return None
         self.ctx.wait()
