@@ -320,10 +320,38 @@ class GltfMeshLoader:
 
 
 # ----------------------------------------------------------------------------------------------- EXR (scanline, no compression)
-def write_exr(path, rgb: np.ndarray) -> None:
-    """RGB float32 image -> uncompressed scanline OpenEXR (channels B,G,R as FLOAT)."""
+def _exr_zip_pack(raw: bytes) -> bytes:
+    """OpenEXR ZIP/ZIPS block: de-interleave even/odd bytes, delta-predict, deflate."""
+    import zlib
+
+    a = np.frombuffer(raw, np.uint8)
+    t = np.concatenate([a[0::2], a[1::2]]).astype(np.int16)
+    d = t.copy()
+    d[1:] = (t[1:] - t[:-1] + 128 + 256) % 256
+    return zlib.compress(d.astype(np.uint8).tobytes(), 6)
+
+
+def _exr_zip_unpack(comp: bytes, size: int) -> bytes:
+    import zlib
+
+    d = np.frombuffer(zlib.decompress(comp), np.uint8).astype(np.int64)
+    if len(d) != size:
+        raise ValueError("EXR ZIP block has the wrong size")
+    d[1:] -= 128
+    t = (np.cumsum(d) % 256).astype(np.uint8)
+    half = (size + 1) // 2
+    out = np.empty(size, np.uint8)
+    out[0::2] = t[:half]
+    out[1::2] = t[half:]
+    return out.tobytes()
+
+
+def write_exr(path, rgb: np.ndarray, compression: str = "none") -> None:
+    """RGB float32 image -> scanline OpenEXR (channels B,G,R as FLOAT); compression "none" | "zips" | "zip"."""
     rgb = np.asarray(rgb, np.float32)
     h, w, _ = rgb.shape
+    if compression != "none":
+        return _write_exr_zip(path, rgb, 16 if compression == "zip" else 1)
 
     def attr(name, typ, payload):
         return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(payload)) + payload
@@ -344,8 +372,43 @@ def write_exr(path, rgb: np.ndarray) -> None:
             f.write(np.ascontiguousarray(rgb[y, :, ::-1].T, "<f4").tobytes())
 
 
+def _exr_header(w, h, comp_code):
+    def attr(name, typ, payload):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(payload)) + payload
+
+    chl = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", 2, 0, 0, 0, 0, 1, 1) for n in ("B", "G", "R")) + b"\0"
+    box = struct.pack("<iiii", 0, 0, w - 1, h - 1)
+    hdr = (attr("channels", "chlist", chl) + attr("compression", "compression", bytes([comp_code])) + attr("dataWindow", "box2i", box)
+           + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0") + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0))
+           + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0.0, 0.0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0")
+    return struct.pack("<II", 20000630, 2) + hdr
+
+
+def _write_exr_zip(path, rgb, lines_per_block):
+    h, w, _ = rgb.shape
+    head = _exr_header(w, h, 3 if lines_per_block == 16 else 2)
+    blocks = []
+    for y0 in range(0, h, lines_per_block):
+        rows = rgb[y0 : y0 + lines_per_block]
+        raw = b"".join(np.ascontiguousarray(r[:, ::-1].T, "<f4").tobytes() for r in rows)  # per scanline: B row, G row, R row
+        comp = _exr_zip_pack(raw)
+        if len(comp) >= len(raw):
+            comp = raw  # the format stores a block raw when deflate does not help
+        blocks.append(struct.pack("<iI", y0, len(comp)) + comp)
+    table0 = len(head) + 8 * len(blocks)
+    offs, o = [], table0
+    for b in blocks:
+        offs.append(o)
+        o += len(b)
+    with open(path, "wb") as f:
+        f.write(head)
+        f.write(np.array(offs, "<u8").tobytes())
+        for b in blocks:
+            f.write(b)
+
+
 def read_exr(path) -> np.ndarray:
-    """Uncompressed scanline EXR with FLOAT or HALF channels -> (h, w, 3) float32 RGB (missing channels = 0)."""
+    """Scanline EXR (uncompressed, ZIPS or ZIP) with FLOAT or HALF channels -> (h, w, 3) float32 RGB (missing channels = 0)."""
     data = Path(path).read_bytes()
     magic, ver = struct.unpack_from("<II", data, 0)
     if magic != 20000630:
@@ -359,8 +422,10 @@ def read_exr(path) -> np.ndarray:
         (ln,) = struct.unpack_from("<I", data, p); p += 4
         attrs[name] = (typ, data[p : p + ln]); p += ln
     p += 1
-    if attrs["compression"][1][0] != 0:
-        raise ValueError(f"{path}: only uncompressed EXR is supported in this round (compression={attrs['compression'][1][0]})")
+    comp = attrs["compression"][1][0]
+    if comp not in (0, 2, 3):
+        raise ValueError(f"{path}: EXR compression {comp} is not supported (uncompressed, ZIPS and ZIP are; PIZ / PXR24 / B44 / DWA are not)")
+    lines_per_block = {0: 1, 2: 1, 3: 16}[comp]
     chans, q, cl = [], 0, attrs["channels"][1]
     while cl[q] != 0:
         e = cl.index(b"\0", q); nm = cl[q:e].decode(); q = e + 1
@@ -368,20 +433,131 @@ def read_exr(path) -> np.ndarray:
         chans.append((nm, pt))
     x0, y0, x1, y1 = struct.unpack("<iiii", attrs["dataWindow"][1])
     w, h = x1 - x0 + 1, y1 - y0 + 1
-    offs = np.frombuffer(data, "<u8", h, p)
+    n_blocks = (h + lines_per_block - 1) // lines_per_block
+    offs = np.frombuffer(data, "<u8", n_blocks, p)
     out = np.zeros((h, w, 3), np.float32)
+    line_bytes = sum({1: 2, 2: 4}.get(pt, 4) for _, pt in chans) * w
     for o in offs:
-        y, _ = struct.unpack_from("<iI", data, int(o)); q = int(o) + 8
-        for nm, pt in chans:
-            if pt == 2:
-                row = np.frombuffer(data, "<f4", w, q); q += 4 * w
-            elif pt == 1:
-                row = np.frombuffer(data, "<f2", w, q).astype(np.float32); q += 2 * w
-            else:
-                row = np.frombuffer(data, "<u4", w, q).astype(np.float32); q += 4 * w
-            if nm in "RGB":
-                out[y - y0, :, "RGB".index(nm)] = row
+        y, size = struct.unpack_from("<iI", data, int(o))
+        n_lines = min(lines_per_block, y1 + 1 - y)
+        block = data[int(o) + 8 : int(o) + 8 + size]
+        if comp and size < line_bytes * n_lines:
+            block = _exr_zip_unpack(block, line_bytes * n_lines)
+        q = 0
+        for ly in range(n_lines):
+            for nm, pt in chans:
+                if pt == 2:
+                    row = np.frombuffer(block, "<f4", w, q); q += 4 * w
+                elif pt == 1:
+                    row = np.frombuffer(block, "<f2", w, q).astype(np.float32); q += 2 * w
+                else:
+                    row = np.frombuffer(block, "<u4", w, q).astype(np.float32); q += 4 * w
+                if nm in "RGB":
+                    out[y + ly - y0, :, "RGB".index(nm)] = row
     return out
+
+
+# ----------------------------------------------------------------------------------------------- bincode processed-asset cache
+class _Bincode:
+    """bincode 2 `standard().with_variable_int_encoding().with_big_endian()` (assets/mod.rs:135-137)."""
+
+    def __init__(self, data: bytes):
+        self.d, self.p = data, 0
+
+    def take(self, n):
+        b = self.d[self.p : self.p + n]
+        if len(b) != n:
+            raise ValueError("bincode: unexpected end of data")
+        self.p += n
+        return b
+
+    def varint(self):
+        b = self.take(1)[0]
+        if b < 251:
+            return b
+        return int.from_bytes(self.take({251: 2, 252: 4, 253: 8, 254: 16}[b]), "big")
+
+    def f16(self):
+        return float(np.frombuffer(self.take(2), ">f2")[0])
+
+
+@dataclass
+class ProcessedMesh:
+    """`Mesh` as serialised by `MeshSaver` (assets/mod.rs:118-125,299-314)."""
+
+    meshlets: np.ndarray  # (n, 4) uint32: vertex_offset, triangle_offset, vertex_count, triangle_count
+    materials: list  # Material
+    vertices: np.ndarray  # (n, 8) float32
+    indices: np.ndarray  # uint8, meshlet-local
+    uploaded: bool
+
+
+def read_processed_mesh(path, layout: str = "current") -> ProcessedMesh:
+    """Decode a file of bevy's processed-asset cache (`imported_assets/Default/*.glb`).
+    layout "current" = field order of assets/mod.rs:118-125 (meshlets, materials, vertices, indices, uploaded);
+    layout "old"     = the order of the file the reference tree still ships: two leading vectors (both empty
+                       there: meshlets and meshlet-local indices), materials, vertices, uploaded.
+    Material = f16 BE metallic, f16 BE roughness, 3 x f16 BE colour, varint u16 texture offset (assets/mod.rs:61-73); the
+    reference's decoder re-reads the metallic bytes as roughness (:88,110) -- that bug is not reproduced."""
+    r = _Bincode(Path(path).read_bytes())
+
+    def meshlets():
+        n = r.varint()
+        return np.array([[r.varint() for _ in range(4)] for _ in range(n)], np.uint32).reshape(n, 4)
+
+    def materials():
+        out = []
+        for _ in range(r.varint()):
+            metal, rough = r.f16(), r.f16()
+            col = (r.f16(), r.f16(), r.f16())
+            tex = r.varint()
+            out.append(Material(col, metal, rough, (0.0, 0.0, 0.0), -1 if tex == 0xFFFF else tex))
+        return out
+
+    def vertices():
+        n = r.varint()
+        return np.frombuffer(r.take(32 * n), ">f4").reshape(n, 8).astype(np.float32)
+
+    def bytes_vec():
+        n = r.varint()
+        return np.frombuffer(r.take(n), np.uint8).copy()
+
+    if layout == "current":
+        ml, mats, verts, idx = meshlets(), materials(), vertices(), bytes_vec()
+    elif layout == "old":
+        ml, idx = meshlets(), bytes_vec()
+        mats, verts = materials(), vertices()
+    else:
+        raise ValueError("layout must be 'current' or 'old'")
+    uploaded = bool(r.take(1)[0])
+    if r.p != len(r.d):
+        raise ValueError(f"bincode: {len(r.d) - r.p} trailing bytes (wrong layout?)")
+    return ProcessedMesh(ml, mats, verts, idx, uploaded)
+
+
+def write_processed_mesh(path, pm: ProcessedMesh) -> None:
+    """Serialise in the CURRENT layout (MeshSaver, assets/mod.rs:299-314)."""
+
+    def varint(v):
+        if v < 251:
+            return bytes([v])
+        for tag, n in ((251, 2), (252, 4), (253, 8)):
+            if v < (1 << (8 * n)):
+                return bytes([tag]) + int(v).to_bytes(n, "big")
+        raise ValueError("varint too large")
+
+    out = bytearray(varint(len(pm.meshlets)))
+    for m in pm.meshlets:
+        for v in m:
+            out += varint(int(v))
+    out += varint(len(pm.materials))
+    for m in pm.materials:
+        out += np.array([m.metalic_factor, m.roughness_factor, *m.color], ">f2").tobytes()
+        out += varint(0xFFFF if m.texture_offset < 0 else m.texture_offset)
+    out += varint(len(pm.vertices)) + np.ascontiguousarray(pm.vertices, ">f4").tobytes()
+    out += varint(len(pm.indices)) + bytes(np.asarray(pm.indices, np.uint8))
+    out += bytes([1 if pm.uploaded else 0])
+    Path(path).write_bytes(bytes(out))
 
 
 def load_bluenoise(path=None) -> np.ndarray:

@@ -183,3 +183,36 @@ def test_glb_node_transforms_are_baked(tmp_path):
     assert np.allclose(m.vertices[:3, 3:6], [0, 0, 1])  # flat normal generated, transformed by the inverse transpose
     assert np.allclose(m.geometries["base_color"][1], [0.1, 0.2, 0.3, 1]) and np.isclose(m.geometries["roughness"][1], 0.5)
     assert np.allclose(m.geometries["emission"][1][:3], 3.0) and np.isclose(m.geometries["metallic_factor"][1], 0.25)
+
+
+def test_exr_zip_roundtrip(tmp_path):
+    sky = scenes.sky(96, 40)  # 40 rows: ZIP blocks of 16 scanlines with a ragged last block
+    for comp in ("zips", "zip"):
+        p = tmp_path / f"{comp}.exr"
+        assets.write_exr(p, sky, compression=comp)
+        assert p.stat().st_size < sky.nbytes  # it really compresses
+        assert np.array_equal(assets.read_exr(p), sky)
+
+
+def test_processed_asset_cache_decodes_the_reference_fixture(tmp_path):
+    """tests/golden/processed_box.glb.bin is the reference tree's own imported_assets/Default/box.glb (6253 B, data):
+    bincode 2, big-endian, varint, OLD field order: 8 materials + 192 vertices of 8 unit cubes."""
+    pm = assets.read_processed_mesh(ROOT / "tests" / "golden" / "processed_box.glb.bin", layout="old")
+    assert len(pm.meshlets) == 0 and len(pm.indices) == 0 and pm.uploaded is False
+    assert len(pm.materials) == 8 and pm.vertices.shape == (192, 8)
+    cols = np.array([m.color for m in pm.materials])
+    assert np.allclose(cols[0], 0.8, atol=1e-3) and np.allclose(cols[5], 0.5, atol=1e-3)
+    assert np.allclose(cols[2], (0, 0, 0.8), atol=1e-3) and np.allclose(cols[3], (0.8, 0, 0.006), atol=1e-3) and np.allclose(cols[4], (0.009, 0.8, 0), atol=1e-3)
+    assert [round(m.roughness_factor, 3) for m in pm.materials] == [1.0] * 7 + [0.5]
+    assert all(m.texture_offset == -1 and m.metalic_factor == 0.0 for m in pm.materials)
+    assert np.all(np.abs(pm.vertices[:, :3]) == 1.0)  # unit cubes: positions +-1
+    assert np.allclose(np.linalg.norm(pm.vertices[:, 3:6], axis=1), 1.0)  # per-face normals
+    with pytest.raises(ValueError):
+        assets.read_processed_mesh(ROOT / "tests" / "golden" / "processed_box.glb.bin", layout="current")
+    # current layout round trip (MeshSaver / MeshLoader, assets/mod.rs:151-168,299-314)
+    pm2 = assets.ProcessedMesh(np.array([[0, 0, 64, 124], [64, 372, 3, 1]], np.uint32), pm.materials, pm.vertices, np.arange(300, dtype=np.uint8), True)
+    q = tmp_path / "m.bin"
+    assets.write_processed_mesh(q, pm2)
+    back = assets.read_processed_mesh(q)
+    assert np.array_equal(back.meshlets, pm2.meshlets) and np.array_equal(back.vertices, pm2.vertices) and np.array_equal(back.indices, pm2.indices)
+    assert back.uploaded is True and [m.color for m in back.materials] == [m.color for m in pm2.materials]
