@@ -860,8 +860,8 @@ static inline int slab(const float *bx, const float o[3], const float inv[3], fl
 }
 #define ORC_STACK 256
 #define ORC_EMPTY 0xFFFFFFFFu
-/* Closest / any hit.  Children are visited nearest first (ties: lower slot), the others are pushed so that they pop in
- * ascending entry distance; no re-cull on pop.  A leaf reference holds 1..8 triangles, tested in order. */
+/* Closest / any hit.  Children are visited nearest first (ties: lower slot; four-wide any-hit: plain slot order), the
+ * others are pushed so that they pop in that order; no re-cull on pop.  A leaf reference holds 1..8 triangles, tested in order. */
 static void traverse(const orc_scene *s, const float o[3], const float d[3], float tmin, float tmax, int any,
                      hit_t *out, uint32_t *cn, uint32_t *ct) {
     hit_t best = {tmax, 0.0f, 0.0f, ORC_MISS};
@@ -895,7 +895,9 @@ static void traverse(const orc_scene *s, const float o[3], const float d[3], flo
                     if (QN && r != ORC_EMPTY) dequantize_slot((const uint32_t *)nd, k, qbox);
                     if (r != ORC_EMPTY && slab(QN ? qbox : nd + 8 * k, o, inv, tmin, best.t, &t)) {
                         int p = nh++;
-                        while (p > 0 && t < tn[p - 1]) { tn[p] = tn[p - 1]; ref[p] = ref[p - 1]; p--; } /* stable: ties keep slot order */
+                        /* closest hit: nearest first, stable (ties keep slot order).  any hit: occlusion does not depend on
+                         * the visiting order, the entered slots are simply taken in slot order (no sort in the kernel) */
+                        while (!any && p > 0 && t < tn[p - 1]) { tn[p] = tn[p - 1]; ref[p] = ref[p - 1]; p--; }
                         tn[p] = t; ref[p] = r;
                     }
                 }

@@ -209,12 +209,20 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
                 Cand c0{h0 ? t0 : kInf, h0 ? r0 : kEmptySlot, 0u}, c1{h1 ? t1 : kInf, h1 ? r1 : kEmptySlot, 1u};
                 Cand c2{h2 ? t2 : kInf, h2 ? r2 : kEmptySlot, 2u}, c3{h3 ? t3 : kInf, h3 ? r3 : kEmptySlot, 3u};
                 const uint32_t nh = (uint32_t)h0 + (uint32_t)h1 + (uint32_t)h2 + (uint32_t)h3;
-                // 5-comparator sorting network on (tn, slot); non-hits carry tn = +inf and sink to the end
-                cswap(c0, c1);
-                cswap(c2, c3);
-                cswap(c0, c2);
-                cswap(c1, c3);
-                cswap(c1, c2);
+                if (ANY) {
+                    // any-hit: occlusion does not depend on the visiting order, so skip the sort and just compact the
+                    // entered slots to the front (slot order)
+                    if (!h2) { c2 = c3; c3.ref = kEmptySlot; }
+                    if (!h1) { c1 = c2; c2 = c3; c3.ref = kEmptySlot; }
+                    if (!h0) { c0 = c1; c1 = c2; c2 = c3; c3.ref = kEmptySlot; }
+                } else {
+                    // 5-comparator sorting network on (tn, slot); non-hits carry tn = +inf and sink to the end
+                    cswap(c0, c1);
+                    cswap(c2, c3);
+                    cswap(c0, c2);
+                    cswap(c1, c3);
+                    cswap(c1, c2);
+                }
                 if (nh > 3) {
                     if (r.sp < kLdsStack) lds[r.sp * kExtendBlock] = c3.ref;
                     else spill[r.sp - kLdsStack] = c3.ref;
