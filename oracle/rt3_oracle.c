@@ -885,21 +885,29 @@ static void traverse(const orc_scene *s, const float o[3], const float d[3], flo
                 continue;
             }
             nn++;
-            uint32_t ref[4]; float tn[4]; int nh = 0;
+            uint32_t ref[4]; int nh = 0;
             if (W4) {
                 const int QN = (int)s->node_quant;
                 const float *nd = s->nodes + (QN ? 16 : 32) * (size_t)cur;
+                float ct[4]; uint32_t cr[4];
                 for (int k = 0; k < 4; k++) {
                     float qbox[6];
                     uint32_t r = QN ? ((const uint32_t *)nd)[10 + k] : f2u(nd[8 * k + 6]); float t;
                     if (QN && r != ORC_EMPTY) dequantize_slot((const uint32_t *)nd, k, qbox);
-                    if (r != ORC_EMPTY && slab(QN ? qbox : nd + 8 * k, o, inv, tmin, best.t, &t)) {
-                        int p = nh++;
-                        /* closest hit: nearest first, stable (ties keep slot order).  any hit: occlusion does not depend on
-                         * the visiting order, the entered slots are simply taken in slot order (no sort in the kernel) */
-                        while (!any && p > 0 && t < tn[p - 1]) { tn[p] = tn[p - 1]; ref[p] = ref[p - 1]; p--; }
-                        tn[p] = t; ref[p] = r;
+                    int h = r != ORC_EMPTY && slab(QN ? qbox : nd + 8 * k, o, inv, tmin, best.t, &t);
+                    ct[k] = h ? t : INFINITY; cr[k] = h ? r : ORC_EMPTY;
+                    nh += h;
+                }
+                if (any) { /* any hit: occlusion does not depend on the visiting order -> entered slots in slot order, no sort */
+                    int w = 0;
+                    for (int k = 0; k < 4; k++) if (cr[k] != ORC_EMPTY) ref[w++] = cr[k];
+                } else {   /* closest hit: the kernel's 5-comparator network on the entry distance (strict <) */
+                    static const int net[5][2] = {{0, 1}, {2, 3}, {0, 2}, {1, 3}, {1, 2}};
+                    for (int c = 0; c < 5; c++) {
+                        int a = net[c][0], b = net[c][1];
+                        if (ct[b] < ct[a]) { float tt = ct[a]; ct[a] = ct[b]; ct[b] = tt; uint32_t rr = cr[a]; cr[a] = cr[b]; cr[b] = rr; }
                     }
+                    for (int k = 0; k < nh; k++) ref[k] = cr[k];
                 }
             } else {
                 const float *nd = s->nodes + 16 * (size_t)cur;

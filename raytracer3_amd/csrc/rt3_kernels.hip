@@ -23,19 +23,20 @@ constexpr uint32_t kMaxSteps = 1u << 20;  // safety bound on traversal steps per
 
 constexpr uint32_t kEmptySlot = 0xFFFFFFFFu;
 
-struct Cand {  // a child slot that the ray enters: entry distance + reference, ordered by (tn, slot)
+struct Cand {  // a child slot that the ray enters: entry distance + reference
     float tn;
-    uint32_t ref, slot;
+    uint32_t ref;
 };
+// compare-exchange on the entry distance alone (strict <).  Equal distances are ordered by the fixed 5-comparator
+// network itself; the oracle runs the identical network, so the visiting order is the same on both sides.
 __device__ __forceinline__ void cswap(Cand& a, Cand& b) {
-    bool sw = b.tn < a.tn || (b.tn == a.tn && b.slot < a.slot);
-    Cand t = a;
+    bool sw = b.tn < a.tn;
+    float ta = a.tn;
+    uint32_t ra = a.ref;
     a.tn = sw ? b.tn : a.tn;
     a.ref = sw ? b.ref : a.ref;
-    a.slot = sw ? b.slot : a.slot;
-    b.tn = sw ? t.tn : b.tn;
-    b.ref = sw ? t.ref : b.ref;
-    b.slot = sw ? t.slot : b.slot;
+    b.tn = sw ? ta : b.tn;
+    b.ref = sw ? ra : b.ref;
 }
 __device__ __forceinline__ void pin(float4& q) { asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w)); }
 // branch-free form of tri_test (same arithmetic, same acceptance rule): no early-outs, so the three loads of a
@@ -65,8 +66,8 @@ __device__ __forceinline__ void tri_test_nb(float4 q0, float4 q1, float4 q2, V3 
 // loop spent ~49 iterations per 64 rays whose mean length is ~23 steps.
 //
 // Layouts: kLayoutBinary64 (two fp32 boxes), kLayoutWide128 (four fp32 boxes), kLayoutWide64Q (four 8-bit boxes).
-// Children are visited nearest first (ties: lower slot); the others are pushed so that they pop in ascending entry
-// distance; no re-cull on pop.  A leaf reference holds 1..8 consecutive triangles.
+// Closest hit: children are visited nearest first, the others are pushed so that they pop in ascending entry distance
+// (order fixed by a 5-comparator network); any hit: plain slot order.  No re-cull on pop.  A leaf reference holds 1..8 consecutive triangles.
 // Every step makes exactly ONE memory round trip: a lane first fetches its next item -- the node, or the next
 // triangle(s) of its current leaf -- with one batch of 16-byte loads issued together, then branches into box or
 // triangle tests (both branch-free).
@@ -206,8 +207,8 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
                     h2 = slab_test_hw(v3(q4.x, q4.y, q4.z), v3(q4.w, q5.x, q5.y), o, inv, tmin, r.best.t, t2) & (r2 != kEmptySlot);
                     h3 = slab_test_hw(v3(q6.x, q6.y, q6.z), v3(q6.w, q7.x, q7.y), o, inv, tmin, r.best.t, t3) & (r3 != kEmptySlot);
                 }
-                Cand c0{h0 ? t0 : kInf, h0 ? r0 : kEmptySlot, 0u}, c1{h1 ? t1 : kInf, h1 ? r1 : kEmptySlot, 1u};
-                Cand c2{h2 ? t2 : kInf, h2 ? r2 : kEmptySlot, 2u}, c3{h3 ? t3 : kInf, h3 ? r3 : kEmptySlot, 3u};
+                Cand c0{h0 ? t0 : kInf, h0 ? r0 : kEmptySlot}, c1{h1 ? t1 : kInf, h1 ? r1 : kEmptySlot};
+                Cand c2{h2 ? t2 : kInf, h2 ? r2 : kEmptySlot}, c3{h3 ? t3 : kInf, h3 ? r3 : kEmptySlot};
                 const uint32_t nh = (uint32_t)h0 + (uint32_t)h1 + (uint32_t)h2 + (uint32_t)h3;
                 if (ANY) {
                     // any-hit: occlusion does not depend on the visiting order, so skip the sort and just compact the
@@ -216,7 +217,7 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
                     if (!h1) { c1 = c2; c2 = c3; c3.ref = kEmptySlot; }
                     if (!h0) { c0 = c1; c1 = c2; c2 = c3; c3.ref = kEmptySlot; }
                 } else {
-                    // 5-comparator sorting network on (tn, slot); non-hits carry tn = +inf and sink to the end
+                    // 5-comparator sorting network on tn; non-hits carry tn = +inf and sink to the end
                     cswap(c0, c1);
                     cswap(c2, c3);
                     cswap(c0, c2);
