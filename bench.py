@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--node-width", type=int, default=0, help="2 | 4 (0 = library default)")
     ap.add_argument("--node-quant", type=int, default=-1, help="0 | 1 (-1 = library default)")
     ap.add_argument("--refill", type=int, default=-1, help="traversal tuning: idle lanes before a wave refills (RT3_OPT_EXTEND_VARIANT)")
+    ap.add_argument("--flags", type=int, default=-1, help="GConst.pad[0] feature flags (-1 = the full estimator); experiments only")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-crop", type=str, default="960x540")
     args = ap.parse_args()
@@ -102,7 +103,7 @@ def main():
         torch.cuda.synchronize()
 
     def frame(i):
-        g = pt.make_gconst(cam, args.spp, args.bounces, frame=i, flags=DEFAULT_FLAGS)
+        g = pt.make_gconst(cam, args.spp, args.bounces, frame=i, flags=DEFAULT_FLAGS if args.flags < 0 else args.flags)
         pt.render(g, postprocess=False, wait=False)
         return pt.gather_light(dist, torch) if world > 1 else None, g
 
