@@ -252,7 +252,7 @@ int ensure_work(rt3_ctx* c, size_t paths, size_t npix) {
         }
         if (int r = dev_alloc(c, &c->hits, 4 * P)) return r;
         if (int r = dev_alloc(c, &c->sh_rays, 8 * P)) return r;
-        if (int r = dev_alloc(c, &c->sh_contrib, 3 * P)) return r;
+        if (int r = dev_alloc(c, &c->sh_contrib, 4 * P)) return r;  // {rgb, path id} records
         if (int r = dev_alloc(c, &c->sh_pid, P)) return r;
         if (int r = dev_alloc(c, &c->lacc, 3 * P)) return r;
         c->cap = P;
@@ -938,7 +938,16 @@ int rt3_trace_rays(rt3_ctx* c, const float* rays, uint32_t n, int any_hit, float
         TR(hipMalloc((void**)&d_cn, (size_t)n * 4));
         TR(hipMalloc((void**)&d_ct, (size_t)n * 4));
     }
-    TR(hipMemcpy(d_rays, rays, (size_t)n * 32, hipMemcpyHostToDevice));
+    {  // host SoA (ox..tmax) -> device records {o.xyz, tmin} x n, {d.xyz, tmax} x n
+        std::vector<float> rec((size_t)n * 8);
+        for (uint32_t i = 0; i < n; i++) {
+            float* a = &rec[4 * (size_t)i];
+            float* b = &rec[4 * ((size_t)n + i)];
+            a[0] = rays[i]; a[1] = rays[(size_t)n + i]; a[2] = rays[2 * (size_t)n + i]; a[3] = rays[6 * (size_t)n + i];
+            b[0] = rays[3 * (size_t)n + i]; b[1] = rays[4 * (size_t)n + i]; b[2] = rays[5 * (size_t)n + i]; b[3] = rays[7 * (size_t)n + i];
+        }
+        TR(hipMemcpy(d_rays, rec.data(), (size_t)n * 32, hipMemcpyHostToDevice));
+    }
     TR(hipEventCreate(&e0));
     TR(hipEventCreate(&e1));
     if (repeat < 1) repeat = 1;
@@ -960,10 +969,14 @@ int rt3_trace_rays(rt3_ctx* c, const float* rays, uint32_t n, int any_hit, float
     if (any_hit) {
         TR(hipMemcpy(prim, d_occ, (size_t)n * 4, hipMemcpyDeviceToHost));
     } else {
-        TR(hipMemcpy(t, d_hits, (size_t)n * 4, hipMemcpyDeviceToHost));
-        TR(hipMemcpy(u, d_hits + n, (size_t)n * 4, hipMemcpyDeviceToHost));
-        TR(hipMemcpy(v, d_hits + 2 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost));
-        TR(hipMemcpy(prim, d_hits + 3 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost));
+        std::vector<float> rec((size_t)n * 4);  // device hits are {t, u, v, prim} records
+        TR(hipMemcpy(rec.data(), d_hits, (size_t)n * 16, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < n; i++) {
+            t[i] = rec[4 * (size_t)i];
+            u[i] = rec[4 * (size_t)i + 1];
+            v[i] = rec[4 * (size_t)i + 2];
+            memcpy(&prim[i], &rec[4 * (size_t)i + 3], 4);
+        }
     }
     if (n_nodes) TR(hipMemcpy(n_nodes, d_cn, (size_t)n * 4, hipMemcpyDeviceToHost));
     if (n_tris) TR(hipMemcpy(n_tris, d_ct, (size_t)n * 4, hipMemcpyDeviceToHost));

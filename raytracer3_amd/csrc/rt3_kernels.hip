@@ -4,8 +4,9 @@
 //   k_raygen -> k_extend -> k_gbuffer                                   ("gbuffer" pass)
 //   k_shade<first> -> [k_shadow] -> k_extend -> k_shade -> ... -> k_accumulate   ("refrence_mode" pass)
 //   k_postprocess                                                        ("postprocess" pass)
-// All queues are structure-of-arrays so that lane i touches element i of each stream (coalesced 256 B per
-// wave-instruction); live rays are compacted with __ballot / popcount, one atomic per wave.
+// All queues are structure-of-arrays of 16-byte records (ray = {o, tmin} + {d, tmax}, state = {T, pdf}, hit = {t, u, v, prim},
+// shadow contribution = {rgb, path id}): lane i touches record i of each stream, 1 KiB per wave instruction, the widest
+// coalesced access; live rays are compacted with __ballot / popcount, one atomic per workgroup.
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
@@ -110,10 +111,11 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
         if (m_idle != 0ull && pool_next < pool_end && ((uint32_t)__popcll(m_idle) >= kRefillLanes || m_idle == ~0ull)) {
             const uint32_t idx = pool_next + (uint32_t)__popcll(m_idle & lanes_below);
             if (!busy && idx < pool_end) {
-                r.o = v3(rays[idx], rays[stride + idx], rays[2 * stride + idx]);
-                r.d = v3(rays[3 * stride + idx], rays[4 * stride + idx], rays[5 * stride + idx]);
-                r.tmin = rays[6 * stride + idx];
-                r.best = Hit{rays[7 * stride + idx], 0.0f, 0.0f, kMiss};
+                const float4 ro = reinterpret_cast<const float4*>(rays)[idx], rd = reinterpret_cast<const float4*>(rays)[stride + idx];
+                r.o = v3(ro.x, ro.y, ro.z);
+                r.d = v3(rd.x, rd.y, rd.z);
+                r.tmin = ro.w;
+                r.best = Hit{rd.w, 0.0f, 0.0f, kMiss};
                 r.inv = v3(guarded_inverse(r.d.x), guarded_inverse(r.d.y), guarded_inverse(r.d.z));
                 r.cur = 0u;
                 r.leaf_k = 0u;
@@ -280,7 +282,8 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
     }
 }
 
-// closest-hit over a ray queue.  rays: 8 SoA streams of `stride` floats; hits: t,u,v,prim streams of `stride`.
+// closest-hit over a ray queue.  rays: two float4 streams of `stride` records, {o.xyz, tmin} then {d.xyz, tmax};
+// hits: one float4 {t, u, v, prim} per ray.  16-byte records are the widest coalesced access (1 KiB per wave instruction).
 template <bool COUNT, int LAYOUT>
 __global__ __launch_bounds__(kExtendBlock) void k_extend(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                                          const float* __restrict__ rays, size_t stride,
@@ -291,10 +294,9 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(const float4* __restric
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
     unsigned long long tot_n = 0, tot_t = 0;
     trace_stream<false, COUNT, LAYOUT>(nodes, tris, rays, stride, n, stack + threadIdx.x, [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct) {
-        hits[i] = h.t;
-        hits[stride + i] = h.u;
-        hits[2 * stride + i] = h.v;
-        reinterpret_cast<uint32_t*>(hits)[3 * stride + i] = h.prim;
+        // one 16-byte record per ray: with persistent waves rays finish out of order, four SoA streams would be four
+        // scattered partial-line writes
+        reinterpret_cast<float4*>(hits)[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
         if (COUNT) {
             if (cnt_nodes) cnt_nodes[i] = cn;
             if (cnt_tris) cnt_tris[i] = ct;
@@ -325,10 +327,11 @@ __global__ __launch_bounds__(kExtendBlock) void k_shadow(const float4* __restric
         if (occluded_out) {
             occluded_out[i] = h.prim != kMiss ? 1u : 0u;
         } else if (h.prim == kMiss) {
-            uint32_t p = pid[i];
-            lacc[p] += contrib[i];
-            lacc[lstride + p] += contrib[stride + i];
-            lacc[2 * lstride + p] += contrib[2 * stride + i];
+            const float4 c = reinterpret_cast<const float4*>(contrib)[i];  // {rgb, path id}
+            uint32_t p = __float_as_uint(c.w);
+            lacc[p] += c.x;
+            lacc[lstride + p] += c.y;
+            lacc[2 * lstride + p] += c.z;
         }
         if (COUNT) {
             if (cnt_nodes) cnt_nodes[i] = cn;
@@ -350,14 +353,8 @@ __global__ void k_raygen(GConstDev g, const uint32_t* __restrict__ pixels, uint3
         uint32_t xy = pixels[i];
         V3 o, d;
         primary_ray(g, xy & 0xFFFFu, xy >> 16, o, d);
-        rays[i] = o.x;
-        rays[stride + i] = o.y;
-        rays[2 * stride + i] = o.z;
-        rays[3 * stride + i] = d.x;
-        rays[4 * stride + i] = d.y;
-        rays[5 * stride + i] = d.z;
-        rays[6 * stride + i] = 0.0f;               // TMin, gbuffer_helpers.slang:100
-        rays[7 * stride + i] = kBackgroundDepth;   // TMax, :101
+        reinterpret_cast<float4*>(rays)[i] = make_float4(o.x, o.y, o.z, 0.0f);                         // TMin, gbuffer_helpers.slang:100
+        reinterpret_cast<float4*>(rays)[stride + i] = make_float4(d.x, d.y, d.z, kBackgroundDepth);    // TMax, :101
     }
 }
 // gbuffer.slang:15-20
@@ -366,13 +363,14 @@ __global__ void k_gbuffer(SceneDev sc, const uint32_t* __restrict__ pixels, uint
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
         uint32_t xy = pixels[i];
         size_t pi = (size_t)(xy >> 16) * width + (xy & 0xFFFFu);
-        uint32_t prim = reinterpret_cast<const uint32_t*>(hits)[3 * stride + i];
+        const float4 hrec = reinterpret_cast<const float4*>(hits)[i];
+        uint32_t prim = __float_as_uint(hrec.w);
         if (prim == kMiss) {
             depth[pi] = kBackgroundDepth;
         } else {
-            Surface s = hit_info(sc, prim, hits[stride + i], hits[2 * stride + i]);
+            Surface s = hit_info(sc, prim, hrec.y, hrec.z);
             gbuffer[pi] = gbuffer_pack(s);
-            depth[pi] = hits[i];
+            depth[pi] = hrec.x;
         }
     }
 }
@@ -496,11 +494,14 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
                 }
             }
         } else if (active) {
-            o = v3(a.in_rays[i], a.in_rays[S + i], a.in_rays[2 * S + i]);
-            d = v3(a.in_rays[3 * S + i], a.in_rays[4 * S + i], a.in_rays[5 * S + i]);
-            T = v3(a.in_T[i], a.in_T[S + i], a.in_T[2 * S + i]);
-            pdf_b = a.in_T[3 * S + i];
-            uint32_t prim = reinterpret_cast<const uint32_t*>(a.in_hits)[3 * S + i];
+            const float4 ro = reinterpret_cast<const float4*>(a.in_rays)[i], rd = reinterpret_cast<const float4*>(a.in_rays)[S + i];
+            const float4 tp = reinterpret_cast<const float4*>(a.in_T)[i];
+            o = v3(ro.x, ro.y, ro.z);
+            d = v3(rd.x, rd.y, rd.z);
+            T = v3(tp.x, tp.y, tp.z);
+            pdf_b = tp.w;
+            const float4 hrec = reinterpret_cast<const float4*>(a.in_hits)[i];
+            uint32_t prim = __float_as_uint(hrec.w);
             if (prim == kMiss) {  // :37-40 ; sky through MIS (north_star)
                 if (nee && pdf_b > 0.0f) {
                     float su, sv;
@@ -514,8 +515,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
                 }
                 active = false;
             } else {
-                t = a.in_hits[i];
-                surf = hit_info(a.sc, prim, a.in_hits[S + i], a.in_hits[2 * S + i]);  // :55
+                t = hrec.x;
+                surf = hit_info(a.sc, prim, hrec.y, hrec.z);  // :55
             }
         }
         bool emit_shadow = false, emit_ext = false;
@@ -597,33 +598,15 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
         const BlockAppend slot = block_append2(emit_ext, a.out_count, emit_shadow, a.sh_count, append_lds);
         if (emit_shadow) {
             const uint32_t j = slot.sh;
-            a.sh_rays[j] = o.x;
-            a.sh_rays[S + j] = o.y;
-            a.sh_rays[2 * S + j] = o.z;
-            a.sh_rays[3 * S + j] = wl.x;
-            a.sh_rays[4 * S + j] = wl.y;
-            a.sh_rays[5 * S + j] = wl.z;
-            a.sh_rays[6 * S + j] = kRayTMin;
-            a.sh_rays[7 * S + j] = kBackgroundDepth;
-            a.sh_contrib[j] = contrib.x;
-            a.sh_contrib[S + j] = contrib.y;
-            a.sh_contrib[2 * S + j] = contrib.z;
-            a.sh_pid[j] = pid;
+            reinterpret_cast<float4*>(a.sh_rays)[j] = make_float4(o.x, o.y, o.z, kRayTMin);
+            reinterpret_cast<float4*>(a.sh_rays)[S + j] = make_float4(wl.x, wl.y, wl.z, kBackgroundDepth);
+            reinterpret_cast<float4*>(a.sh_contrib)[j] = make_float4(contrib.x, contrib.y, contrib.z, __uint_as_float(pid));
         }
         if (emit_ext) {
             const uint32_t j = slot.ext;
-            a.out_rays[j] = o.x;
-            a.out_rays[S + j] = o.y;
-            a.out_rays[2 * S + j] = o.z;
-            a.out_rays[3 * S + j] = nd.x;
-            a.out_rays[4 * S + j] = nd.y;
-            a.out_rays[5 * S + j] = nd.z;
-            a.out_rays[6 * S + j] = kRayTMin;         // :31
-            a.out_rays[7 * S + j] = kBackgroundDepth;
-            a.out_T[j] = Tn.x;
-            a.out_T[S + j] = Tn.y;
-            a.out_T[2 * S + j] = Tn.z;
-            a.out_T[3 * S + j] = pdf_n;
+            reinterpret_cast<float4*>(a.out_rays)[j] = make_float4(o.x, o.y, o.z, kRayTMin);  // :31
+            reinterpret_cast<float4*>(a.out_rays)[S + j] = make_float4(nd.x, nd.y, nd.z, kBackgroundDepth);
+            reinterpret_cast<float4*>(a.out_T)[j] = make_float4(Tn.x, Tn.y, Tn.z, pdf_n);
             a.out_pid[j] = pid;
         }
     }
