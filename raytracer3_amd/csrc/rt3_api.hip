@@ -254,7 +254,7 @@ int ensure_work(rt3_ctx* c, size_t paths, size_t npix) {
         if (int r = dev_alloc(c, &c->sh_rays, 8 * P)) return r;
         if (int r = dev_alloc(c, &c->sh_contrib, 4 * P)) return r;  // {rgb, path id} records
         if (int r = dev_alloc(c, &c->sh_pid, P)) return r;
-        if (int r = dev_alloc(c, &c->lacc, 3 * P)) return r;
+        if (int r = dev_alloc(c, &c->lacc, 4 * P)) return r;  // float4 per path
         c->cap = P;
     }
     if (npix > c->cap_pix) {

@@ -329,9 +329,9 @@ __global__ __launch_bounds__(kExtendBlock) void k_shadow(const float4* __restric
         } else if (h.prim == kMiss) {
             const float4 c = reinterpret_cast<const float4*>(contrib)[i];  // {rgb, path id}
             uint32_t p = __float_as_uint(c.w);
-            lacc[p] += c.x;
-            lacc[lstride + p] += c.y;
-            lacc[2 * lstride + p] += c.z;
+            float4* L = reinterpret_cast<float4*>(lacc) + p;  // one 16-byte read-modify-write per path
+            float4 v = *L;
+            *L = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, 0.0f);
         }
         if (COUNT) {
             if (cnt_nodes) cnt_nodes[i] = cn;
@@ -444,7 +444,7 @@ struct ShadeArgs {
     float* sh_contrib;
     uint32_t* sh_pid;
     uint32_t* sh_count;
-    float* lacc;             // 3 streams of `stride`, indexed by path id
+    float* lacc;             // float4 {r, g, b, -} per path id
     size_t stride;
 };
 
@@ -483,9 +483,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
                 size_t pi = (size_t)py * a.width + px;
                 float d0 = a.depth[pi];
                 if (d0 == kBackgroundDepth) {  // :18-21
-                    a.lacc[pid] = 0.0f;
-                    a.lacc[S + pid] = 0.0f;
-                    a.lacc[2 * S + pid] = 0.0f;
+                    reinterpret_cast<float4*>(a.lacc)[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                     active = false;
                 } else {
                     surf = gbuffer_unpack(a.gbuffer[pi]);  // :23
@@ -509,9 +507,9 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
                     V3 rad = sky_eval(a.sc, su, sv);
                     float pl = sky_pdf(a.sc, su, sv);
                     float w = pdf_b / (pdf_b + pl);
-                    a.lacc[pid] += T.x * (rad.x * w);
-                    a.lacc[S + pid] += T.y * (rad.y * w);
-                    a.lacc[2 * S + pid] += T.z * (rad.z * w);
+                    float4* Lp = reinterpret_cast<float4*>(a.lacc) + pid;
+                    float4 lv = *Lp;
+                    *Lp = make_float4(lv.x + T.x * (rad.x * w), lv.y + T.y * (rad.y * w), lv.z + T.z * (rad.z * w), 0.0f);
                 }
                 active = false;
             } else {
@@ -553,13 +551,11 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
             o = v3(o.x + t * d.x, o.y + t * d.y, o.z + t * d.z);  // :47
             // :50 radiance += ray_color * emissive.  x + (+0) == x exactly, so non-emitters skip the read-modify-write.
             if (FIRST) {  // L starts at 0 and T = 1: 0 + 1 * e == e
-                a.lacc[pid] = T.x * surf.emissive.x;
-                a.lacc[S + pid] = T.y * surf.emissive.y;
-                a.lacc[2 * S + pid] = T.z * surf.emissive.z;
+                reinterpret_cast<float4*>(a.lacc)[pid] = make_float4(T.x * surf.emissive.x, T.y * surf.emissive.y, T.z * surf.emissive.z, 0.0f);
             } else if (surf.emissive.x != 0.0f || surf.emissive.y != 0.0f || surf.emissive.z != 0.0f) {
-                a.lacc[pid] += T.x * surf.emissive.x;
-                a.lacc[S + pid] += T.y * surf.emissive.y;
-                a.lacc[2 * S + pid] += T.z * surf.emissive.z;
+                float4* Lp = reinterpret_cast<float4*>(a.lacc) + pid;
+                float4 lv = *Lp;
+                *Lp = make_float4(lv.x + T.x * surf.emissive.x, lv.y + T.y * surf.emissive.y, lv.z + T.z * surf.emissive.z, 0.0f);
             }
             if (nee) {
                 float ul0 = uniform_float(seed, base + 3), ul1 = uniform_float(seed, base + 4);
@@ -624,9 +620,10 @@ __global__ void k_accumulate(GConstDev g, const uint32_t* __restrict__ pixels, u
         float r = first_batch ? 0.0f : radsum[i], gg = first_batch ? 0.0f : radsum[npix + i], bb = first_batch ? 0.0f : radsum[2 * (size_t)npix + i];
         for (uint32_t s = 0; s < sb; s++) {
             size_t p = (size_t)s * npix + i;
-            r += lacc[p];
-            gg += lacc[stride + p];
-            bb += lacc[2 * stride + p];
+            const float4 lv = reinterpret_cast<const float4*>(lacc)[p];
+            r += lv.x;
+            gg += lv.y;
+            bb += lv.z;
         }
         if (!last_batch) {
             radsum[i] = r;
