@@ -374,10 +374,12 @@ int pass_gbuffer(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y, const 
         ScopedTimer t(c, CAT_OTHER);
         launch_raygen(c->stream, gd, pl->dev, pl->count, c->rays[0], S);
     }
+    uint32_t wc_slot;
+    if (int r = reserve_counters(c, 1, &wc_slot)) return r;  // ray-pool cursor of the launch
     {
         ScopedTimer t(c, CAT_EXTEND);
         launch_extend(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->rays[0], S, nullptr, pl->count, pl->count, c->hits, nullptr, nullptr,
-                      c->opt_count ? c->d_totals : nullptr);
+                      c->opt_count ? c->d_totals : nullptr, c->d_counters + wc_slot);
     }
     c->primary_rays_pending += pl->count;
     {
@@ -420,9 +422,10 @@ int pass_reference_mode(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y,
         const uint32_t nsb = std::min(sb, Sspp - s0);
         const uint32_t n_first = nsb * npix;
         uint32_t first;
-        if (int r = reserve_counters(c, 2 * B, &first)) return r;
+        if (int r = reserve_counters(c, 4 * B, &first)) return r;
         uint32_t* ext_cnt = c->d_counters + first;   // [b] = extension rays emitted at bounce b (b < B-1)
         uint32_t* sh_cnt = c->d_counters + first + B;  // [b] = shadow rays emitted at bounce b
+        uint32_t* pool_cur = c->d_counters + first + 2 * B;  // [b], [B + b]: ray-pool cursors of the k_extend / k_shadow launch of bounce b
         c->pending_counters.push_back(CounterBlock{first, B, B});
         int cur = 0;
         for (uint32_t bn = 0; bn < B; bn++) {
@@ -442,12 +445,12 @@ int pass_reference_mode(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y,
             if (nee) {
                 ScopedTimer t(c, CAT_SHADOW);
                 launch_shadow(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->sh_rays, S, sh_cnt + bn, 0, n_first, c->sh_contrib, c->sh_pid,
-                              c->lacc, S, nullptr, nullptr, nullptr, c->opt_count ? c->d_totals + 2 : nullptr);
+                              c->lacc, S, nullptr, nullptr, nullptr, c->opt_count ? c->d_totals + 2 : nullptr, pool_cur + B + bn);
             }
             if (bn != B - 1) {
                 ScopedTimer t(c, CAT_EXTEND);
                 launch_extend(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->rays[cur], S, ext_cnt + bn, 0, n_first, c->hits, nullptr, nullptr,
-                              c->opt_count ? c->d_totals : nullptr);
+                              c->opt_count ? c->d_totals : nullptr, pool_cur + bn);
             }
         }
         {
@@ -913,12 +916,12 @@ int rt3_trace_rays(rt3_ctx* c, const float* rays, uint32_t n, int any_hit, float
     if (n == 0) return RT3_OK;
     HIPC(c, hipSetDevice(c->device));
     float *d_rays = nullptr, *d_hits = nullptr;
-    uint32_t *d_cn = nullptr, *d_ct = nullptr, *d_occ = nullptr;
+    uint32_t *d_cn = nullptr, *d_ct = nullptr, *d_occ = nullptr, *d_cur = nullptr;
     const bool count = n_nodes || n_tris;
     int rc = RT3_OK;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto cleanup = [&]() {
-        (void)hipFree(d_rays); (void)hipFree(d_hits); (void)hipFree(d_cn); (void)hipFree(d_ct); (void)hipFree(d_occ);
+        (void)hipFree(d_rays); (void)hipFree(d_hits); (void)hipFree(d_cn); (void)hipFree(d_ct); (void)hipFree(d_occ); (void)hipFree(d_cur);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
     };
@@ -934,6 +937,7 @@ int rt3_trace_rays(rt3_ctx* c, const float* rays, uint32_t n, int any_hit, float
     TR(hipMalloc((void**)&d_rays, (size_t)n * 32));
     TR(hipMalloc((void**)&d_hits, (size_t)n * 16));
     TR(hipMalloc((void**)&d_occ, (size_t)n * 4));
+    TR(hipMalloc((void**)&d_cur, 4));
     if (count) {
         TR(hipMalloc((void**)&d_cn, (size_t)n * 4));
         TR(hipMalloc((void**)&d_ct, (size_t)n * 4));
@@ -952,10 +956,11 @@ int rt3_trace_rays(rt3_ctx* c, const float* rays, uint32_t n, int any_hit, float
     TR(hipEventCreate(&e1));
     if (repeat < 1) repeat = 1;
     auto launch = [&]() {
+        (void)hipMemsetAsync(d_cur, 0, 4, c->stream);  // ray-pool cursor
         if (any_hit)
-            launch_shadow(c->stream, count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, d_rays, n, nullptr, n, n, nullptr, nullptr, nullptr, 0, d_occ, d_cn, d_ct, nullptr);
+            launch_shadow(c->stream, count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, d_rays, n, nullptr, n, n, nullptr, nullptr, nullptr, 0, d_occ, d_cn, d_ct, nullptr, d_cur);
         else
-            launch_extend(c->stream, count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, d_rays, n, nullptr, n, n, d_hits, d_cn, d_ct, nullptr);
+            launch_extend(c->stream, count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, d_rays, n, nullptr, n, n, d_hits, d_cn, d_ct, nullptr, d_cur);
     };
     launch();  // warm-up (also the result-producing launch)
     TR(hipEventRecord(e0, c->stream));

@@ -72,6 +72,7 @@ __device__ __forceinline__ void tri_test_nb(float4 q0, float4 q1, float4 q2, V3 
 // Every step makes exactly ONE memory round trip: a lane first fetches its next item -- the node, or the next
 // triangle(s) of its current leaf -- with one batch of 16-byte loads issued together, then branches into box or
 // triangle tests (both branch-free).
+constexpr uint32_t kPoolChunk = 1024;
 __constant__ uint32_t g_refill_lanes = 12;  // tuning knob (RT3_OPT_EXTEND_VARIANT)
 void set_refill_lanes(uint32_t v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_refill_lanes), &v, 4); }
 
@@ -85,15 +86,15 @@ struct LaneRay {  // traversal state of the ray a lane currently owns
 
 template <bool ANY, bool COUNT, int LAYOUT, typename Finish>
 __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, const float4* __restrict__ tris,
-                                             const float* __restrict__ rays, size_t stride, uint32_t n, uint32_t* __restrict__ lds,
-                                             Finish finish) {
+                                             const float* __restrict__ rays, size_t stride, uint32_t n, uint32_t* __restrict__ work_counter,
+                                             uint32_t* __restrict__ lds, Finish finish) {
     constexpr bool WIDE = LAYOUT == kLayoutWide128;   // 8 x 16 B per fetch
     constexpr bool WIDEQ = LAYOUT == kLayoutWide64Q;  // 4 x 16 B per fetch, quantised boxes
-    // this wave's pool: a contiguous, 64-aligned slice of the queue
-    const uint32_t waves_total = gridDim.x * (kExtendBlock / 64), wave_id = blockIdx.x * (kExtendBlock / 64) + (threadIdx.x >> 6);
-    const uint32_t per_wave = (((n + waves_total - 1) / waves_total) + 63u) & ~63u;
-    uint32_t pool_next = wave_id * per_wave < n ? wave_id * per_wave : n;
-    const uint32_t pool_end = pool_next + per_wave < n ? pool_next + per_wave : n;
+    // ray pool: waves grab chunks of kPoolChunk consecutive rays from a per-launch counter (one returning atomic per
+    // chunk: ~30 k per launch, far below the ~88 / us a single counter word sustains), so no wave idles at the end of a
+    // launch while another still owns untouched rays
+    uint32_t pool_next = 0, pool_end = 0;
+    bool queue_empty = false;
     const uint32_t lane = __lane_id();
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
     const uint32_t kRefillLanes = g_refill_lanes;
@@ -108,6 +109,14 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
     for (;;) {
         // ---- refill idle lanes from the pool
         const unsigned long long m_idle = __ballot(!busy);
+        if (pool_next >= pool_end && !queue_empty && m_idle != 0ull) {  // grab the next chunk (wave-uniform)
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(work_counter, kPoolChunk);
+            base = __builtin_amdgcn_readfirstlane(base);
+            queue_empty = base >= n;
+            pool_next = base < n ? base : n;
+            pool_end = base + kPoolChunk < n ? base + kPoolChunk : n;
+        }
         if (m_idle != 0ull && pool_next < pool_end && ((uint32_t)__popcll(m_idle) >= kRefillLanes || m_idle == ~0ull)) {
             const uint32_t idx = pool_next + (uint32_t)__popcll(m_idle & lanes_below);
             if (!busy && idx < pool_end) {
@@ -133,7 +142,7 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
             pool_next = pool_next + taken < pool_end ? pool_next + taken : pool_end;
         }
         if (__ballot(busy) == 0ull) {
-            if (pool_next >= pool_end) break;
+            if (pool_next >= pool_end && queue_empty) break;
             continue;
         }
         if (!busy) continue;
@@ -289,11 +298,12 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(const float4* __restric
                                                          const float* __restrict__ rays, size_t stride,
                                                          const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
                                                          float* __restrict__ hits, uint32_t* __restrict__ cnt_nodes,
-                                                         uint32_t* __restrict__ cnt_tris, unsigned long long* __restrict__ totals) {
+                                                         uint32_t* __restrict__ cnt_tris, unsigned long long* __restrict__ totals,
+                                                         uint32_t* __restrict__ work_counter) {
     __shared__ uint32_t stack[kLdsStack * kExtendBlock];
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
     unsigned long long tot_n = 0, tot_t = 0;
-    trace_stream<false, COUNT, LAYOUT>(nodes, tris, rays, stride, n, stack + threadIdx.x, [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct) {
+    trace_stream<false, COUNT, LAYOUT>(nodes, tris, rays, stride, n, work_counter, stack + threadIdx.x, [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct) {
         // one 16-byte record per ray: with persistent waves rays finish out of order, four SoA streams would be four
         // scattered partial-line writes
         reinterpret_cast<float4*>(hits)[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
@@ -319,11 +329,12 @@ __global__ __launch_bounds__(kExtendBlock) void k_shadow(const float4* __restric
                                                          const float* __restrict__ contrib, const uint32_t* __restrict__ pid,
                                                          float* __restrict__ lacc, size_t lstride,
                                                          uint32_t* __restrict__ occluded_out, uint32_t* __restrict__ cnt_nodes,
-                                                         uint32_t* __restrict__ cnt_tris, unsigned long long* __restrict__ totals) {
+                                                         uint32_t* __restrict__ cnt_tris, unsigned long long* __restrict__ totals,
+                                                         uint32_t* __restrict__ work_counter) {
     __shared__ uint32_t stack[kLdsStack * kExtendBlock];
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
     unsigned long long tot_n = 0, tot_t = 0;
-    trace_stream<true, COUNT, LAYOUT>(nodes, tris, rays, stride, n, stack + threadIdx.x, [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct) {
+    trace_stream<true, COUNT, LAYOUT>(nodes, tris, rays, stride, n, work_counter, stack + threadIdx.x, [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct) {
         if (occluded_out) {
             occluded_out[i] = h.prim != kMiss ? 1u : 0u;
         } else if (h.prim == kMiss) {
@@ -796,10 +807,11 @@ void launch_raygen(hipStream_t st, const GConstDev& g, const uint32_t* pixels, u
 }
 void launch_extend(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float* rays, size_t stride,
                    const uint32_t* count_ptr, uint32_t count_imm, uint32_t max_n, float* hits, uint32_t* cn, uint32_t* ct,
-                   unsigned long long* totals) {
+                   unsigned long long* totals, uint32_t* work_counter) {
     unsigned grid = grid_for(max_n, kExtendBlock, kExtendMaxBlocks);
 #define RT3_LAUNCH_EXTEND(C, L)                                                                                                                  \
-    hipLaunchKernelGGL((k_extend<C, L>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, hits, cn, ct, totals)
+    hipLaunchKernelGGL((k_extend<C, L>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, hits, cn, ct, totals, \
+                       work_counter)
     if (count) {
         if (layout == kLayoutWide64Q) RT3_LAUNCH_EXTEND(true, kLayoutWide64Q);
         else if (layout == kLayoutWide128) RT3_LAUNCH_EXTEND(true, kLayoutWide128);
@@ -813,11 +825,11 @@ void launch_extend(hipStream_t st, bool count, int layout, const float4* nodes, 
 }
 void launch_shadow(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float* rays, size_t stride,
                    const uint32_t* count_ptr, uint32_t count_imm, uint32_t max_n, const float* contrib, const uint32_t* pid, float* lacc,
-                   size_t lstride, uint32_t* occluded_out, uint32_t* cn, uint32_t* ct, unsigned long long* totals) {
+                   size_t lstride, uint32_t* occluded_out, uint32_t* cn, uint32_t* ct, unsigned long long* totals, uint32_t* work_counter) {
     unsigned grid = grid_for(max_n, kExtendBlock, kExtendMaxBlocks);
 #define RT3_LAUNCH_SHADOW(C, L)                                                                                                                \
     hipLaunchKernelGGL((k_shadow<C, L>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, contrib, pid, lacc, \
-                       lstride, occluded_out, cn, ct, totals)
+                       lstride, occluded_out, cn, ct, totals, work_counter)
     if (count) {
         if (layout == kLayoutWide64Q) RT3_LAUNCH_SHADOW(true, kLayoutWide64Q);
         else if (layout == kLayoutWide128) RT3_LAUNCH_SHADOW(true, kLayoutWide128);
