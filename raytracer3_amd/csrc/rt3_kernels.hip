@@ -72,7 +72,7 @@ __device__ __forceinline__ void tri_test_nb(float4 q0, float4 q1, float4 q2, V3 
 // Every step makes exactly ONE memory round trip: a lane first fetches its next item -- the node, or the next
 // triangle(s) of its current leaf -- with one batch of 16-byte loads issued together, then branches into box or
 // triangle tests (both branch-free).
-constexpr uint32_t kPoolChunk = 1024;
+constexpr uint32_t kPoolChunk = 256;
 __constant__ uint32_t g_refill_lanes = 12;  // tuning knob (RT3_OPT_EXTEND_VARIANT)
 void set_refill_lanes(uint32_t v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_refill_lanes), &v, 4); }
 
@@ -91,7 +91,8 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
     constexpr bool WIDE = LAYOUT == kLayoutWide128;   // 8 x 16 B per fetch
     constexpr bool WIDEQ = LAYOUT == kLayoutWide64Q;  // 4 x 16 B per fetch, quantised boxes
     // ray pool: waves grab chunks of kPoolChunk consecutive rays from a per-launch counter (one returning atomic per
-    // chunk: ~30 k per launch, far below the ~88 / us a single counter word sustains), so no wave idles at the end of a
+    // chunk: ~110 k per launch, ~20 / us, below the ~88 / us a single counter word sustains; 64-ray chunks were
+    // atomic-bound, 1024 and more left a visible tail), so no wave idles at the end of a
     // launch while another still owns untouched rays
     uint32_t pool_next = 0, pool_end = 0;
     bool queue_empty = false;
