@@ -48,6 +48,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-crop", type=str, default="960x540")
     args = ap.parse_args()
+    default_workload = (args.gpus == 1 and (args.width, args.height, args.spp, args.bounces, args.detail) == (1920, 1080, 64, 4, 1.0)
+                        and args.batch_spp == 0 and args.leaf_size == 0 and args.node_width == 0 and args.node_quant == -1
+                        and args.refill == -1 and args.flags == -1)
 
     import numpy as np
     import torch
@@ -145,9 +148,21 @@ def main():
     launches_per_frame = st.extend_launches / max(args.steps, 1)
     achieved = bytes_per_frame / (ext_ms_per_frame * 1e-3) / 1e9 if ext_ms_per_frame > 0 else 0.0
     peak = 8000.0
+    # HBM-side bytes per k_extend launch cannot be counted from inside this process: they come from separate
+    # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command (tools/profile_round.sh), corrected as
+    # MI355X_MICROARCH.md prescribes by tools/summarize_profile.py and committed under profiles/. Only quoted for the
+    # default workload they were collected on; null otherwise.
+    traffic, traffic_src = None, None
+    tfiles = sorted((ROOT / "profiles").glob("*_traffic.json"))
+    if tfiles and default_workload:
+        tj = json.loads(tfiles[-1].read_text())
+        kk = [v for k, v in tj["kernels"].items() if k.startswith("rt3::k_extend<false")]
+        if kk:
+            traffic = round(kk[0]["hbm_bytes_per_launch"])
+            traffic_src = f"profiles/{tfiles[-1].name}: {tj['correction']}"
     roofline = {
         "kernel": "k_extend", "bound": "hbm", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s", "frac": round(achieved / peak, 4),
-        "traffic": None,  # HBM bytes from rocprofv3 PMC passes: see profiles/ and DESIGN.md (not collectable inside bench.py)
+        "traffic": traffic, "traffic_source": traffic_src,
         "launches_per_frame": launches_per_frame, "avg_launch_ms": round(ext_ms_per_frame / max(launches_per_frame, 1), 4),
         "algorithmic_bytes_per_launch": round(bytes_per_frame / max(launches_per_frame, 1)),
         "bytes_per_ray_formula": f"48 + {node_bytes}*n_nodes + 48*n_tris", "bvh": {"nodes": n_nodes, "node_bytes": node_bytes, "tris": n_tris, "levels": levels},
