@@ -176,7 +176,8 @@ int rt3_trace_rays(rt3_ctx *ctx, const float *rays, uint32_t n, int any_hit, flo
 /* ---- device self-test: evaluates one device function per element so known-answer tests can pin the GPU arithmetic.
  *      op: 0 hash(u32) 1 zcurve(x,y) 2 murmur3(seed,index) 3 uniform_float(seed,index) 4 gbuffer pack (11 f32 -> 4 u32)
  *      5 gbuffer unpack (4 u32 -> 11 f32) 6 diffuse sample (u0,u1 -> wi) 7 orthonormal basis (n -> b1,b2) 8 AgX (rgb -> rgb)
- *      9 sincos_2pi (u -> sin,cos) 10 atan2 (y,x) 11 rng_seed(px,py,frame).  in/out: host arrays of 32-bit words. ---- */
+ *      9 sincos_2pi (u -> sin,cos) 10 atan2 (y,x) 11 rng_seed(px,py,frame)
+ *      12 division-free integer helpers (n,d -> n/d, n%d, wrap(int(n), (d & 0xFFFF)+1)).  in/out: host arrays of 32-bit words. ---- */
 int rt3_selftest_eval(rt3_ctx *ctx, int op, const void *in, uint32_t n, void *out);
 
 int rt3_stats_reset(rt3_ctx *ctx);

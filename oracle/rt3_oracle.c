@@ -432,9 +432,9 @@ orc_scene *orc_scene_create(void) {
 void orc_accel_set_layout(orc_scene *s, uint32_t leaf_max, uint32_t node_width, uint32_t quantized) {
     s->leaf_max = leaf_max < 1 ? 1 : (leaf_max > 8 ? 8 : leaf_max);
     s->node_width = node_width == 2 ? 2 : 4;
-    s->node_quant = (quantized && s->node_width == 4) ? 1 : 0;
+    s->node_quant = s->node_width == 4 ? (quantized > 2 ? 2 : quantized) : 0; /* 0 fp32 128 B, 1 quantised 64 B, 2 compact 48 B */
 }
-uint32_t orc_accel_node_words(const orc_scene *s) { return (s->node_width == 2 || s->node_quant) ? 16u : 32u; }
+uint32_t orc_accel_node_words(const orc_scene *s) { return s->node_width == 2 ? 16u : (s->node_quant == 2 ? 12u : (s->node_quant ? 16u : 32u)); }
 
 /* [north_star] 64-byte four-wide node with quantised child boxes:
  *   words 0-2  origin = min corner of the union of the child boxes
@@ -480,7 +480,33 @@ static void quantize_node(const float mn[4][3], const float mx[4][3], const uint
     for (uint32_t k = 0; k < 4; k++) for (int j = 0; j < 6; j++) bytes[6 * k + j] = k < ns ? q[k][j] : (j < 3 ? 255 : 0);
     for (uint32_t k = 0; k < 4; k++) out[10 + k] = k < ns ? ref[k] : 0xFFFFFFFFu;
 }
-static void dequantize_slot(const uint32_t *nd, int k, float box[6]) {
+/* Compact 48-byte node (node_quant 2): words 0..9 as above, but the four references are implied.  The internal children of
+ * a node are numbered consecutively from node_base and the triangles of its leaf children are stored consecutively from
+ * tri_base (both in slot order), so a child is described by one nibble: 0 = internal node, 8 | (count-1) = leaf of 1..8
+ * triangles, 7 = empty slot.  Nibbles of slots 0,1 sit in bits 24..31 of word 3, slot 2 / 3 in the top nibble of
+ * word 10 (node_base, 28 bits) / word 11 (tri_base, 28 bits).  Three 16-byte loads per node instead of four. */
+static void compact_node(const float mn[4][3], const float mx[4][3], const uint32_t meta[4], uint32_t ns, uint32_t node_base,
+                         uint32_t tri_base, uint32_t out[12]) {
+    uint32_t tmp[16], ref[4] = {0, 0, 0, 0};
+    quantize_node(mn, mx, ref, ns, tmp);
+    memcpy(out, tmp, 40);
+    uint32_t m[4];
+    for (uint32_t k = 0; k < 4; k++) m[k] = k < ns ? meta[k] : 7u;
+    out[3] |= (m[0] << 24) | (m[1] << 28);
+    out[10] = (node_base & 0x0FFFFFFFu) | (m[2] << 28);
+    out[11] = (tri_base & 0x0FFFFFFFu) | (m[3] << 28);
+}
+static void compact_refs(const uint32_t *nd, uint32_t ref[4]) {
+    uint32_t m[4] = {(nd[3] >> 24) & 15u, nd[3] >> 28, nd[10] >> 28, nd[11] >> 28};
+    uint32_t nb = nd[10] & 0x0FFFFFFFu, tb = nd[11] & 0x0FFFFFFFu;
+    for (int k = 0; k < 4; k++) {
+        if (m[k] == 0u) ref[k] = nb++;
+        else if (m[k] & 8u) { uint32_t c = (m[k] & 7u) + 1u; ref[k] = 0x80000000u | ((c - 1u) << 28) | tb; tb += c; }
+        else ref[k] = 0xFFFFFFFFu;
+    }
+}
+/* the decode expression quantize_node() is conservative to (documentation; traversal folds it into the ray, see slab_q) */
+__attribute__((unused)) static void dequantize_slot(const uint32_t *nd, int k, float box[6]) {
     const uint8_t *bytes = (const uint8_t *)(nd + 4);
     for (int a = 0; a < 3; a++) {
         float scale = u2f(((nd[3] >> (8 * a)) & 0xFFu) << 23), org = u2f(nd[a]);
@@ -702,9 +728,10 @@ int orc_accel_build(orc_scene *s) {
         s->nodes = (float *)calloc(words, 4);
         float *nd = s->nodes;
         if (s->node_quant) {
-            float qmn[4][3], qmx[4][3]; uint32_t qref[4] = {0x80000000u, 0, 0, 0};
+            float qmn[4][3], qmx[4][3]; uint32_t qref[4] = {0x80000000u, 0, 0, 0}, qmeta[4] = {8u, 7u, 7u, 7u};
             memcpy(qmn[0], lmin, 12); memcpy(qmx[0], lmax, 12);
-            quantize_node(qmn, qmx, qref, 1, (uint32_t *)nd);
+            if (s->node_quant == 2) compact_node(qmn, qmx, qmeta, 1, 1u, 0u, (uint32_t *)nd);
+            else quantize_node(qmn, qmx, qref, 1, (uint32_t *)nd);
         } else
         for (uint32_t k = 0; k < (W4 ? 4u : 2u); k++) {
             float *mn = W4 ? nd + 8 * k : nd + 6 * k, *mx = mn + 3;
@@ -770,9 +797,42 @@ int orc_accel_build(orc_scene *s) {
         uint32_t *newidx = (uint32_t *)malloc((size_t)nn * 4), kept = 0, maxd = 0;
         for (uint32_t i = 0; i < nn; i++) { newidx[i] = kept; if (ORC_KEEP(i)) kept++; }
         const uint32_t QN = s->node_quant;
-        const uint32_t words = (W4 && !QN) ? 32u : 16u;
+        const uint32_t words = (W4 && !QN) ? 32u : (QN == 2 ? 12u : 16u);
         free(s->nodes);
         s->nodes = (float *)calloc((size_t)kept * words, 4);
+        /* compact layout: node_base / tri_base of every surviving node = exclusive sums (in index order) of its number of
+         * internal child slots / of the triangles in its leaf slots; a child's own index is 1 + node_base(parent) + rank */
+        uint32_t *cbase = NULL, *tbase = NULL; float *tris2 = NULL;
+        if (QN == 2) {
+            cbase = (uint32_t *)malloc((size_t)nn * 4); tbase = (uint32_t *)malloc((size_t)nn * 4);
+            tris2 = (float *)calloc((size_t)n * 12, 4);
+            uint32_t ci = 0, ti = 0;
+            for (uint32_t i = 0; i < nn; i++) {
+                cbase[i] = ci; tbase[i] = ti;
+                if (!ORC_KEEP(i)) continue;
+                uint32_t c2[2] = {left[i], right[i]};
+                for (int c = 0; c < 2; c++) {
+                    uint32_t ch = c2[c], sl[2], m = 0;
+                    if (!(ch & 0x80000000u) && ORC_LIVE(ch)) { sl[m++] = left[ch]; sl[m++] = right[ch]; } else sl[m++] = ch;
+                    for (uint32_t k = 0; k < m; k++) {
+                        if (sl[k] & 0x80000000u) ti += 1;
+                        else if (ORC_LIVE(sl[k])) ci += 1;
+                        else ti += rcnt[sl[k]];
+                    }
+                }
+            }
+            newidx[0] = 0;
+            for (uint32_t i = 0; i < nn; i++) {
+                if (!ORC_KEEP(i)) continue;
+                uint32_t c2[2] = {left[i], right[i]}, rank = 0;
+                for (int c = 0; c < 2; c++) {
+                    uint32_t ch = c2[c], sl[2], m = 0;
+                    if (!(ch & 0x80000000u) && ORC_LIVE(ch)) { sl[m++] = left[ch]; sl[m++] = right[ch]; } else sl[m++] = ch;
+                    for (uint32_t k = 0; k < m; k++)
+                        if (!(sl[k] & 0x80000000u) && ORC_LIVE(sl[k])) newidx[sl[k]] = 1u + cbase[i] + rank++;
+                }
+            }
+        }
         for (uint32_t i = 0; i < nn; i++) {
             if (!ORC_KEEP(i)) continue;
             uint32_t slots[4], ns = 0, c2[2] = {left[i], right[i]};
@@ -782,7 +842,7 @@ int orc_accel_build(orc_scene *s) {
                 else slots[ns++] = ch;
             }
             float *nd = s->nodes + (size_t)words * newidx[i];
-            float qmn[4][3], qmx[4][3]; uint32_t qref[4];
+            float qmn[4][3], qmx[4][3]; uint32_t qref[4], qmeta[4] = {7u, 7u, 7u, 7u}, tcur = QN == 2 ? tbase[i] : 0u;
             for (uint32_t k = 0; k < (W4 ? 4u : 2u); k++) {
                 float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
                 uint32_t ref = 0xFFFFFFFFu;
@@ -794,17 +854,27 @@ int orc_accel_build(orc_scene *s) {
                         ref = ORC_LIVE(ch) ? newidx[ch] : (0x80000000u | ((rcnt[ch] - 1u) << 28) | rlo[ch]);
                     }
                 }
+                if (QN == 2 && k < ns) { /* meta nibble + move the leaf's triangles to their place behind tri_base */
+                    if (ref & 0x80000000u) {
+                        uint32_t first = ref & 0x0FFFFFFFu, cnt = ((ref >> 28) & 7u) + 1u;
+                        qmeta[k] = 8u | (cnt - 1u);
+                        memcpy(tris2 + 12 * (size_t)tcur, s->tris + 12 * (size_t)first, (size_t)cnt * 48);
+                        tcur += cnt;
+                    } else qmeta[k] = 0u;
+                }
                 if (QN) { memcpy(qmn[k], mn, 12); memcpy(qmx[k], mx, 12); qref[k] = ref; }
                 else if (W4) { memcpy(nd + 8 * k, mn, 12); memcpy(nd + 8 * k + 3, mx, 12); nd[8 * k + 6] = u2f(ref); nd[8 * k + 7] = 0.0f; }
                 else { memcpy(nd + 6 * k, mn, 12); memcpy(nd + 6 * k + 3, mx, 12); nd[12 + k] = u2f(ref); }
             }
-            if (QN) quantize_node(qmn, qmx, qref, ns, (uint32_t *)nd);
+            if (QN == 2) compact_node(qmn, qmx, qmeta, ns, 1u + cbase[i], tbase[i], (uint32_t *)nd);
+            else if (QN) quantize_node(qmn, qmx, qref, ns, (uint32_t *)nd);
             uint32_t lvl = (W4 ? depth[i] / 2u : depth[i]) + 2u; /* levels from the root to this node's leaf slots */
             if (!W4) { /* binary: collapsed ancestors do not exist, every live ancestor is a level */ }
             if (lvl > maxd) maxd = lvl;
         }
         s->max_depth = maxd;
         s->n_nodes = kept;
+        if (QN == 2) { free(s->tris); s->tris = tris2; free(cbase); free(tbase); }
 #undef ORC_LIVE
 #undef ORC_KEEP
         free(left); free(right); free(rlo); free(rcnt); free(nmin); free(nmax); free(stack); free(state); free(depth); free(newidx);
@@ -862,6 +932,23 @@ static inline int slab(const float *bx, const float o[3], const float inv[3], fl
 #define ORC_EMPTY 0xFFFFFFFFu
 /* Closest / any hit.  Children are visited nearest first (ties: lower slot; four-wide any-hit: plain slot order), the
  * others are pushed so that they pop in that order; no re-cull on pop.  A leaf reference holds 1..8 triangles, tested in order. */
+/* Quantised nodes: the dequantisation is folded into the ray.  A child plane sits at org + q * step (q = 0..255), so its
+ * ray parameter is ((org + q*step) - o) * inv = q * (step*inv) + (org - o)*inv: per node three products A = step*inv and three
+ * B = (org - o)*inv, per plane ONE fused multiply-add fmaf(q, A, B) (single rounding, the GPU's v_fma_f32).  The rounding
+ * differs from slab() by an amount that corresponds to ~1 ulp of |org - o| in space -- far inside the leaf padding. */
+static inline int slab_q(const uint8_t *qb, const float A[3], const float B[3], float tmin, float tbest, float *tn_out) {
+    float tn = tmin, tf = tbest;
+    for (int k = 0; k < 3; k++) {
+        float t0 = __builtin_fmaf((float)qb[k], A[k], B[k]), t1 = __builtin_fmaf((float)qb[3 + k], A[k], B[k]);
+        float lo = t0 < t1 ? t0 : t1, hi = t0 < t1 ? t1 : t0;
+        tn = lo > tn ? lo : tn;
+        tf = hi < tf ? hi : tf;
+    }
+    *tn_out = tn;
+    return tn <= tf;
+}
+/* target_clones: the "fma" clone inlines fmaf as one vfmadd instruction, the default clone calls libm (same result) */
+__attribute__((target_clones("fma", "default")))
 static void traverse(const orc_scene *s, const float o[3], const float d[3], float tmin, float tmax, int any,
                      hit_t *out, uint32_t *cn, uint32_t *ct) {
     hit_t best = {tmax, 0.0f, 0.0f, ORC_MISS};
@@ -888,13 +975,19 @@ static void traverse(const orc_scene *s, const float o[3], const float d[3], flo
             uint32_t ref[4]; int nh = 0;
             if (W4) {
                 const int QN = (int)s->node_quant;
-                const float *nd = s->nodes + (QN ? 16 : 32) * (size_t)cur;
-                float ct[4]; uint32_t cr[4];
+                const float *nd = s->nodes + (QN == 2 ? 12 : (QN ? 16 : 32)) * (size_t)cur;
+                float ct[4]; uint32_t cr[4], r48[4];
+                float A[3] = {0, 0, 0}, B[3] = {0, 0, 0};
+                if (QN == 2) compact_refs((const uint32_t *)nd, r48);
+                if (QN) for (int a = 0; a < 3; a++) {
+                    const uint32_t *w = (const uint32_t *)nd;
+                    float step = u2f(((w[3] >> (8 * a)) & 0xFFu) << 23);
+                    A[a] = step * inv[a];
+                    B[a] = (nd[a] - o[a]) * inv[a];
+                }
                 for (int k = 0; k < 4; k++) {
-                    float qbox[6];
-                    uint32_t r = QN ? ((const uint32_t *)nd)[10 + k] : f2u(nd[8 * k + 6]); float t;
-                    if (QN && r != ORC_EMPTY) dequantize_slot((const uint32_t *)nd, k, qbox);
-                    int h = r != ORC_EMPTY && slab(QN ? qbox : nd + 8 * k, o, inv, tmin, best.t, &t);
+                    uint32_t r = QN == 2 ? r48[k] : (QN ? ((const uint32_t *)nd)[10 + k] : f2u(nd[8 * k + 6])); float t;
+                    int h = r != ORC_EMPTY && (QN ? slab_q((const uint8_t *)nd + 16 + 6 * k, A, B, tmin, best.t, &t) : slab(nd + 8 * k, o, inv, tmin, best.t, &t));
                     ct[k] = h ? t : INFINITY; cr[k] = h ? r : ORC_EMPTY;
                     nh += h;
                 }

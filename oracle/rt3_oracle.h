@@ -104,14 +104,15 @@ int orc_scene_set_bluenoise(orc_scene *s, const uint8_t *rgba, uint32_t w, uint3
 int orc_scene_set_texture(orc_scene *s, uint32_t index, const uint8_t *rgba_srgb, uint32_t w, uint32_t h); /* hit_logic.slang:31-33 */
 /* LBVH (Karras 2012) over all triangles; replaces raytracing.rs:88-148 */
 /* leaf_max 1..8 triangles per leaf (default 2); node_width 2 = 64 B binary nodes, 4 = four-wide nodes (default);
- * quantized (width 4 only): 64 B nodes with 8-bit conservative child boxes instead of 128 B fp32 boxes */
+ * quantized (width 4 only): 0 = 128 B fp32 boxes, 1 = 64 B nodes with 8-bit conservative child boxes and explicit
+ * references, 2 = compact 48 B nodes (same boxes; references implied by node_base / tri_base + one nibble per child) */
 void orc_accel_set_layout(orc_scene *s, uint32_t leaf_max, uint32_t node_width, uint32_t quantized);
 uint32_t orc_accel_node_words(const orc_scene *s);
 int orc_accel_build(orc_scene *s);
 uint32_t orc_accel_num_tris(const orc_scene *s);
 uint32_t orc_accel_num_nodes(const orc_scene *s);
 const float *orc_accel_nodes(const orc_scene *s);  /* n_nodes x orc_accel_node_words() 32-bit words */
-const float *orc_accel_tris(const orc_scene *s);   /* n_tris  x 12 words (48 B), Morton order */
+const float *orc_accel_tris(const orc_scene *s);   /* n_tris  x 12 words (48 B); Morton order, compact layout: leaf order */
 const uint64_t *orc_accel_codes(const orc_scene *s);
 uint32_t orc_accel_max_depth(const orc_scene *s);
 /* sky tables (for parity checks against the product) */

@@ -3,10 +3,11 @@ device is visible, every entry point raises."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
-LIB_PATH = PKG / "librt3.so"
+LIB_PATH = Path(os.environ.get("RT3_LIBRARY", PKG / "librt3.so"))  # RT3_LIBRARY: another build of the same ABI (kernel experiments)
 
 RT3_OK = 0
 E_INVALID, E_HIP, E_NO_DEVICE, E_STATE, E_UNSUPPORTED, E_DEPTH = -1, -2, -3, -4, -5, -6

@@ -60,8 +60,8 @@ struct rt3_ctx {
     GeometryInfoDev* d_geoms = nullptr;
     uint32_t n_geoms = 0, n_prims = 0;
     uint32_t *d_prim_geom = nullptr, *d_first_prim = nullptr;
-    float *d_sky = nullptr, *d_cdf_cond = nullptr, *d_cdf_marg = nullptr, *d_pdf_uv = nullptr;
-    uint16_t *d_guide_cond = nullptr, *d_guide_marg = nullptr;
+    float *d_sky = nullptr, *d_cdf_cond = nullptr, *d_cdf_marg = nullptr;
+    uint32_t *d_guide_cond = nullptr, *d_guide_marg = nullptr;
     uint32_t sky_w = 0, sky_h = 0;
     uint8_t* d_bn = nullptr;
     uint32_t bn_w = 0, bn_h = 0;
@@ -199,12 +199,13 @@ SceneDev scene_dev(const rt3_ctx* c) {
     s.sky = c->d_sky;
     s.cdf_cond = c->d_cdf_cond;
     s.cdf_marg = c->d_cdf_marg;
-    s.pdf_uv = c->d_pdf_uv;
     s.sky_w = c->sky_w;
     s.sky_h = c->sky_h;
     s.bluenoise = c->d_bn;
     s.bn_w = c->bn_w;
     s.bn_h = c->bn_h;
+    s.bn_w_div = make_fastdiv(c->bn_w);
+    s.bn_h_div = make_fastdiv(c->bn_h);
     s.tex_pixels = c->d_tex_pixels;
     s.tex_table = c->d_tex_table;
     s.srgb_lut = c->d_srgb_lut;
@@ -519,7 +520,7 @@ void rt3_destroy(rt3_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dev_free(c->d_verts); dev_free(c->d_indices); dev_free(c->d_geoms); dev_free(c->d_prim_geom); dev_free(c->d_first_prim);
     dev_free(c->d_tex_pixels); dev_free(c->d_tex_table); dev_free(c->d_srgb_lut);
-    dev_free(c->d_sky); dev_free(c->d_cdf_cond); dev_free(c->d_cdf_marg); dev_free(c->d_pdf_uv); dev_free(c->d_bn);
+    dev_free(c->d_sky); dev_free(c->d_cdf_cond); dev_free(c->d_cdf_marg); dev_free(c->d_bn);
     dev_free(c->bvh.nodes); dev_free(c->bvh.tris); dev_free(c->bvh.tri_shade); dev_free(c->d_guide_cond); dev_free(c->d_guide_marg);
     for (auto& r : c->resources)
         if (r.owned && r.ptr) (void)hipFree(r.ptr);
@@ -557,7 +558,8 @@ int rt3_set_option(rt3_ctx* c, int option, int64_t value) {
             c->accel_built = false;
             return RT3_OK;
         case RT3_OPT_NODE_QUANT:
-            c->opt_node_quant = value != 0;
+            if (value < 0 || value > 2) return fail(c, RT3_E_INVALID, "node quantisation must be 0 (fp32), 1 (64 B) or 2 (compact 48 B)");
+            c->opt_node_quant = (uint32_t)value;
             c->accel_built = false;
             return RT3_OK;
         case RT3_OPT_NODE_WIDTH:
@@ -662,30 +664,53 @@ int rt3_scene_set_sky(rt3_ctx* c, const float* rgb, uint32_t w, uint32_t h) {
     marg[h - 1] = 1.0f;
     const float norm = (float)((double)w * (double)h / total);
     for (size_t i = 0; i < n; i++) pdf[i] *= norm;
-    // guide tables: guide[k] = first index with cdf > k / n, so a lookup starts within one cell of its answer
-    auto build_guide = [](const float* cdf, uint32_t cnt, uint16_t* g) {
+    // guide tables: guide[k] = first index with cdf > k / n, so a lookup of u (cell k = floor(u n)) starts inside
+    // [guide[k-1], guide[k+1]].  Stored per cell as one word lo | hi << 16 (hi clamped to n-1): one load instead of two.
+    auto build_guide = [](const float* cdf, uint32_t cnt, uint32_t* g2) {
+        std::vector<uint32_t> g(cnt + 1);
         uint32_t i = 0;
         for (uint32_t k = 0; k <= cnt; k++) {
             const float thr = (float)k / (float)cnt;
             while (i < cnt - 1 && !(cdf[i] > thr)) i++;
-            g[k] = (uint16_t)i;
+            g[k] = i;
+        }
+        for (uint32_t k = 0; k < cnt; k++) {
+            const uint32_t lo = g[k > 0 ? k - 1 : 0], hi = g[k + 1] > cnt - 1 ? cnt - 1 : g[k + 1];
+            g2[k] = lo | (hi << 16);
         }
     };
-    std::vector<uint16_t> gcond((size_t)h * (w + 1)), gmarg(h + 1);
-    for (uint32_t y = 0; y < h; y++) build_guide(cond.data() + (size_t)y * w, w, gcond.data() + (size_t)y * (w + 1));
+    // CDFs are stored with one leading 0 and three trailing pads (2.0 > any u): cdfp[i + 1] = cdf[i], so that
+    // {cdf[i-1], cdf[i], cdf[i+1], cdf[i+2]} is ONE 16-byte load at cdfp + i for every i (row stride w + 4).
+    std::vector<uint32_t> gcond(n), gmarg(h);
+    for (uint32_t y = 0; y < h; y++) build_guide(cond.data() + (size_t)y * w, w, gcond.data() + (size_t)y * w);
     build_guide(marg.data(), h, gmarg.data());
+    std::vector<float> condp((size_t)h * (w + 4)), margp((size_t)h + 4);
+    for (uint32_t y = 0; y < h; y++) {
+        float* r = condp.data() + (size_t)y * (w + 4);
+        r[0] = 0.0f;
+        std::memcpy(r + 1, cond.data() + (size_t)y * w, (size_t)w * 4);
+        r[w + 1] = r[w + 2] = r[w + 3] = 2.0f;
+    }
+    margp[0] = 0.0f;
+    std::memcpy(margp.data() + 1, marg.data(), (size_t)h * 4);
+    margp[h + 1] = margp[h + 2] = margp[h + 3] = 2.0f;
     if (int r = dev_alloc(c, &c->d_guide_cond, gcond.size())) return r;
     if (int r = dev_alloc(c, &c->d_guide_marg, gmarg.size())) return r;
-    HIPC(c, hipMemcpy(c->d_guide_cond, gcond.data(), gcond.size() * 2, hipMemcpyHostToDevice));
-    HIPC(c, hipMemcpy(c->d_guide_marg, gmarg.data(), gmarg.size() * 2, hipMemcpyHostToDevice));
-    if (int r = dev_alloc(c, &c->d_sky, 3 * n)) return r;
-    if (int r = dev_alloc(c, &c->d_cdf_cond, n)) return r;
-    if (int r = dev_alloc(c, &c->d_pdf_uv, n)) return r;
-    if (int r = dev_alloc(c, &c->d_cdf_marg, (size_t)h)) return r;
-    HIPC(c, hipMemcpy(c->d_sky, rgb, n * 12, hipMemcpyHostToDevice));
-    HIPC(c, hipMemcpy(c->d_cdf_cond, cond.data(), n * 4, hipMemcpyHostToDevice));
-    HIPC(c, hipMemcpy(c->d_pdf_uv, pdf.data(), n * 4, hipMemcpyHostToDevice));
-    HIPC(c, hipMemcpy(c->d_cdf_marg, marg.data(), (size_t)h * 4, hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(c->d_guide_cond, gcond.data(), gcond.size() * 4, hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(c->d_guide_marg, gmarg.data(), gmarg.size() * 4, hipMemcpyHostToDevice));
+    std::vector<float> sky4(4 * n);  // {r, g, b, pdf_uv} per texel
+    for (size_t i = 0; i < n; i++) {
+        sky4[4 * i] = rgb[3 * i];
+        sky4[4 * i + 1] = rgb[3 * i + 1];
+        sky4[4 * i + 2] = rgb[3 * i + 2];
+        sky4[4 * i + 3] = pdf[i];
+    }
+    if (int r = dev_alloc(c, &c->d_sky, 4 * n)) return r;
+    if (int r = dev_alloc(c, &c->d_cdf_cond, condp.size())) return r;
+    if (int r = dev_alloc(c, &c->d_cdf_marg, margp.size())) return r;
+    HIPC(c, hipMemcpy(c->d_sky, sky4.data(), n * 16, hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(c->d_cdf_cond, condp.data(), condp.size() * 4, hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(c->d_cdf_marg, margp.data(), margp.size() * 4, hipMemcpyHostToDevice));
     c->sky_w = w;
     c->sky_h = h;
     return RT3_OK;
@@ -716,9 +741,18 @@ int rt3_scene_set_texture(rt3_ctx* c, uint32_t index, const uint8_t* rgba, uint3
 int rt3_sky_download(rt3_ctx* c, float* cond, float* marg, float* pdf) {
     if (!c || !c->d_sky) return fail(c, RT3_E_STATE, "no sky set");
     size_t n = (size_t)c->sky_w * c->sky_h;
-    if (cond) HIPC(c, hipMemcpy(cond, c->d_cdf_cond, n * 4, hipMemcpyDeviceToHost));
-    if (marg) HIPC(c, hipMemcpy(marg, c->d_cdf_marg, (size_t)c->sky_h * 4, hipMemcpyDeviceToHost));
-    if (pdf) HIPC(c, hipMemcpy(pdf, c->d_pdf_uv, n * 4, hipMemcpyDeviceToHost));
+    // the device copies are padded (one leading 0, three trailing pads per CDF): strip the padding
+    if (cond) {
+        std::vector<float> padded((size_t)c->sky_h * (c->sky_w + 4));
+        HIPC(c, hipMemcpy(padded.data(), c->d_cdf_cond, padded.size() * 4, hipMemcpyDeviceToHost));
+        for (uint32_t y = 0; y < c->sky_h; y++) std::memcpy(cond + (size_t)y * c->sky_w, padded.data() + (size_t)y * (c->sky_w + 4) + 1, (size_t)c->sky_w * 4);
+    }
+    if (marg) HIPC(c, hipMemcpy(marg, c->d_cdf_marg + 1, (size_t)c->sky_h * 4, hipMemcpyDeviceToHost));
+    if (pdf) {  // .w of every texel
+        std::vector<float> sky4(4 * n);
+        HIPC(c, hipMemcpy(sky4.data(), c->d_sky, n * 16, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; i++) pdf[i] = sky4[4 * i + 3];
+    }
     return RT3_OK;
 }
 
@@ -727,6 +761,7 @@ int rt3_accel_build(rt3_ctx* c, uint32_t* out_handle) {
     if (!c) return RT3_E_INVALID;
     HIPC(c, hipSetDevice(c->device));
     if (c->n_prims && (!c->d_verts || !c->d_indices)) return fail(c, RT3_E_STATE, "set vertices, indices and geometry before rt3_accel_build");
+    if (c->n_prims > (1u << 28)) return fail(c, RT3_E_UNSUPPORTED, "more than 2^28 triangles (leaf references hold 28 bits)");
     HIPC(c, hipStreamSynchronize(c->stream));
     dev_free(c->bvh.nodes);
     dev_free(c->bvh.tris);

@@ -36,6 +36,32 @@ RT3_DEV V3 normalize(V3 a) {
     float inv = 1.0f / sqrtf(dot(a, a));
     return a * inv;
 }
+// exact n / d for 32-bit operands without a hardware divide (round-up magic number, Granlund-Montgomery / libdivide
+// "branch-free"): q = umulhi(mul, n); n / d = (((n - q) >> 1) + q) >> shift.  A runtime integer division costs ~30 VALU.
+struct FastDiv {
+    uint32_t d, mul, shift;
+};
+__host__ __device__ inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f{d, 0u, 0u};
+    if (d > 1u) {
+        uint32_t l = 0;
+        while (l < 32u && (1ull << l) < (unsigned long long)d) ++l;  // ceil(log2 d)
+        f.mul = (uint32_t)((((1ull << l) - d) << 32) / d + 1ull);
+        f.shift = l - 1u;
+    }
+    return f;
+}
+RT3_DEV uint32_t fast_div(const FastDiv& f, uint32_t n) {
+    if (f.d <= 1u) return n;
+    const uint32_t q = __umulhi(f.mul, n);
+    return (((n - q) >> 1) + q) >> f.shift;
+}
+// ((x % W) + W) % W.  Texel neighbours of a coordinate in [0, 1] lie within one period of the image, where the wrap is a
+// conditional add; the general form is kept for everything else.
+RT3_DEV int wrap_index(int x, int W) {
+    if ((uint32_t)(x + W) < 3u * (uint32_t)W) return x < 0 ? x + W : (x >= W ? x - W : x);
+    return ((x % W) + W) % W;
+}
 RT3_DEV float fmin_sel(float a, float b) { return a < b ? a : b; }
 RT3_DEV float fmax_sel(float a, float b) { return a > b ? a : b; }
 
@@ -356,15 +382,15 @@ struct SceneDev {
     const float* srgb_lut;       // 256 entries: sRGB EOTF
     uint32_t n_tex;
     // sky
-    const float* sky;            // rgb
-    const float* cdf_cond;
-    const float* cdf_marg;
-    const float* pdf_uv;
-    const uint16_t* guide_cond;  // per row, sky_w + 1 entries: guide_cond[k] = first x with cdf_cond[x] > k / sky_w
-    const uint16_t* guide_marg;  // sky_h + 1 entries
+    const float* sky;            // float4 texels {r, g, b, pdf_uv}
+    const float* cdf_cond;       // padded rows of sky_w + 4: {0, cdf[0..w-1], 2, 2, 2}
+    const float* cdf_marg;       // padded: {0, cdf[0..h-1], 2, 2, 2}
+    const uint32_t* guide_cond;  // per row, sky_w cells: lo | hi << 16 = search bounds of the cell's answers
+    const uint32_t* guide_marg;  // sky_h cells
     uint32_t sky_w, sky_h;
     const uint8_t* bluenoise;
     uint32_t bn_w, bn_h;
+    FastDiv bn_w_div, bn_h_div;
 };
 
 // hit_logic.slang:5-40 (transform = identity, vertex colour = 1).  The three index + three vertex gathers of
@@ -377,10 +403,10 @@ RT3_DEV V3 texture_sample(const SceneDev& sc, uint32_t index, float u, float v) 
     float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
     float xf = floorf(x), yf = floorf(y), fx = x - xf, fy = y - yf;
     int x0 = (int)xf, y0 = (int)yf, x1 = x0 + 1, y1 = y0 + 1;
-    x0 = ((x0 % W) + W) % W;
-    x1 = ((x1 % W) + W) % W;
-    y0 = ((y0 % H) + H) % H;
-    y1 = ((y1 % H) + H) % H;
+    x0 = wrap_index(x0, W);
+    x1 = wrap_index(x1, W);
+    y0 = wrap_index(y0, H);
+    y1 = wrap_index(y1, H);
     const uint32_t p00 = *reinterpret_cast<const uint32_t*>(px + 4 * ((size_t)y0 * W + x0)), p10 = *reinterpret_cast<const uint32_t*>(px + 4 * ((size_t)y0 * W + x1));
     const uint32_t p01 = *reinterpret_cast<const uint32_t*>(px + 4 * ((size_t)y1 * W + x0)), p11 = *reinterpret_cast<const uint32_t*>(px + 4 * ((size_t)y1 * W + x1));
     float o[3];
@@ -414,39 +440,51 @@ RT3_DEV Surface hit_info(const SceneDev& sc, uint32_t prim, float bu, float bv) 
 }
 
 // ------------------------------------------------------------------------------------------------ sky (north_star)
-RT3_DEV V3 sky_eval(const SceneDev& sc, float u, float v) {  // Skybox.SampleLevel(uv, 0): bilinear, wrap u, clamp v
-    if (!sc.sky) return v3(0.0f, 0.0f, 0.0f);
+// Texels are stored as float4 {r, g, b, pdf_uv}: the importance-sampling density of a texel travels with its colour, so
+// a light sample / a miss costs no extra cache line for the pdf (the texel is always one of the four bilinear corners).
+RT3_DEV V3 sky_eval_pdf(const SceneDev& sc, float u, float v, int tx, int ty, float& pdf_texel) {
     int W = (int)sc.sky_w, H = (int)sc.sky_h;
     float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
     float xf = floorf(x), yf = floorf(y);
     float fx = x - xf, fy = y - yf;
     int x0 = (int)xf, y0 = (int)yf, x1 = x0 + 1, y1 = y0 + 1;
-    x0 = ((x0 % W) + W) % W;
-    x1 = ((x1 % W) + W) % W;
+    x0 = wrap_index(x0, W);
+    x1 = wrap_index(x1, W);
     y0 = y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0);
     y1 = y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1);
-    const float* p00 = sc.sky + 3 * ((size_t)y0 * W + x0);
-    const float* p10 = sc.sky + 3 * ((size_t)y0 * W + x1);
-    const float* p01 = sc.sky + 3 * ((size_t)y1 * W + x0);
-    const float* p11 = sc.sky + 3 * ((size_t)y1 * W + x1);
+    const float4* sky = reinterpret_cast<const float4*>(sc.sky);
+    const float4 p00 = sky[(size_t)y0 * W + x0], p10 = sky[(size_t)y0 * W + x1], p01 = sky[(size_t)y1 * W + x0], p11 = sky[(size_t)y1 * W + x1];
+    if (tx >= 0) {
+        const bool in_x = tx == x0 || tx == x1, in_y = ty == y0 || ty == y1;
+        pdf_texel = ty == y0 ? (tx == x0 ? p00.w : p10.w) : (tx == x0 ? p01.w : p11.w);
+        if (!(in_x && in_y)) pdf_texel = sky[(size_t)ty * W + tx].w;  // not reached for (u, v) inside texel (tx, ty)
+    }
+    const float a[3] = {p00.x, p00.y, p00.z}, bq[3] = {p10.x, p10.y, p10.z}, c[3] = {p01.x, p01.y, p01.z}, dq[3] = {p11.x, p11.y, p11.z};
     float o[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        float top = p00[k] * (1.0f - fx) + p10[k] * fx, bot = p01[k] * (1.0f - fx) + p11[k] * fx;
+        float top = a[k] * (1.0f - fx) + bq[k] * fx, bot = c[k] * (1.0f - fx) + dq[k] * fx;
         o[k] = top * (1.0f - fy) + bot * fy;
     }
     return v3(o[0], o[1], o[2]);
 }
-RT3_DEV float sky_pdf(const SceneDev& sc, float u, float v) {
-    if (!sc.sky) return 0.0f;
+RT3_DEV V3 sky_eval(const SceneDev& sc, float u, float v) {  // Skybox.SampleLevel(uv, 0): bilinear, wrap u, clamp v
+    if (!sc.sky) return v3(0.0f, 0.0f, 0.0f);
+    float unused;
+    return sky_eval_pdf(sc, u, v, -1, -1, unused);
+}
+// radiance and solid-angle pdf of the sky sampler for a direction that left the scene (equirect coordinates u, v)
+RT3_DEV V3 sky_eval_and_pdf(const SceneDev& sc, float u, float v, float& pdf) {
     int W = (int)sc.sky_w, H = (int)sc.sky_h;
     int ix = (int)(u * (float)W), iy = (int)(v * (float)H);
     ix = ix < 0 ? 0 : (ix > W - 1 ? W - 1 : ix);
     iy = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);
+    float pt;
+    V3 rad = sky_eval_pdf(sc, u, v, ix, iy, pt);
     float st, ct;
     sincos_2pi(v * 0.5f, st, ct);
-    if (!(st > 0.0f)) return 0.0f;
-    return sc.pdf_uv[(size_t)iy * W + ix] / (2.0f * kPi * kPi * st);
+    pdf = st > 0.0f ? pt / (2.0f * kPi * kPi * st) : 0.0f;
+    return rad;
 }
 RT3_DEV uint32_t cdf_find(const float* cdf, uint32_t n, float u) {  // first index with cdf[i] > u
     uint32_t lo = 0, hi = n - 1;
@@ -457,37 +495,48 @@ RT3_DEV uint32_t cdf_find(const float* cdf, uint32_t n, float u) {  // first ind
     }
     return lo;
 }
-// same result as cdf_find, but the search starts from a guide table (guide[k] = cdf_find(k / n)): u lies in cell
-// k = floor(u n), so the answer is inside [guide[k-1], guide[k+1]] (one cell of slack for the rounding of u n).
-RT3_DEV uint32_t cdf_find_guided(const float* cdf, const uint16_t* guide, uint32_t n, float u) {
+// Same index as cdf_find (first i with cdf[i] > u) plus the bracket {cdf[i-1] (0 for i = 0), cdf[i]}, in two memory
+// round trips: the guide cell of u gives bounds [lo, hi] around the answer; when they are at most two apart (81-93 % of
+// the lookups on the bench sky) ONE unaligned 16-byte load {cdf[lo-1] .. cdf[lo+2]} of the padded CDF holds every
+// candidate and the bracket.  Wider cells fall back to the binary search.  These gathers are what k_shade is bound by.
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+RT3_DEV uint32_t cdf_find_guided(const float* cdfp, const uint32_t* guide, uint32_t n, float u, float& lo_v, float& hi_v) {
     uint32_t k = (uint32_t)(u * (float)n);
     k = k > n - 1 ? n - 1 : k;
-    uint32_t lo = guide[k > 0 ? k - 1 : 0], hi = guide[k + 1];
-    hi = hi > n - 1 ? n - 1 : hi;
+    const uint32_t g = guide[k];
+    uint32_t lo = g & 0xFFFFu, hi = g >> 16;
+    if (hi - lo <= 2u) {
+        const f32x4_u c = *reinterpret_cast<const f32x4_u*>(cdfp + lo);
+        const bool s1 = lo < hi && !(c.y > u);
+        const bool s2 = s1 && lo + 1u < hi && !(c.z > u);
+        lo_v = s2 ? c.z : (s1 ? c.y : c.x);
+        hi_v = s2 ? c.w : (s1 ? c.z : c.y);
+        return lo + (s1 ? 1u : 0u) + (s2 ? 1u : 0u);
+    }
     while (lo < hi) {
         uint32_t mid = (lo + hi) >> 1;
-        if (cdf[mid] > u) hi = mid;
+        if (cdfp[mid + 1] > u) hi = mid;
         else lo = mid + 1;
     }
+    lo_v = cdfp[lo];
+    hi_v = cdfp[lo + 1];
     return lo;
 }
 RT3_DEV void sky_sample(const SceneDev& sc, float u0, float u1, V3& dir, V3& rad, float& pdf) {
     uint32_t W = sc.sky_w, H = sc.sky_h;
-    uint32_t y = cdf_find_guided(sc.cdf_marg, sc.guide_marg, H, u0);
-    float lo = y > 0 ? sc.cdf_marg[y - 1] : 0.0f, hi = sc.cdf_marg[y];
+    float lo, hi;
+    uint32_t y = cdf_find_guided(sc.cdf_marg, sc.guide_marg, H, u0, lo, hi);
     float dv = hi > lo ? (u0 - lo) / (hi - lo) : 0.5f;
-    const float* row = sc.cdf_cond + (size_t)y * W;
-    uint32_t x = cdf_find_guided(row, sc.guide_cond + (size_t)y * (W + 1), W, u1);
-    lo = x > 0 ? row[x - 1] : 0.0f;
-    hi = row[x];
+    uint32_t x = cdf_find_guided(sc.cdf_cond + (size_t)y * (W + 4), sc.guide_cond + (size_t)y * W, W, u1, lo, hi);
     float du = hi > lo ? (u1 - lo) / (hi - lo) : 0.5f;
     float u = ((float)x + du) / (float)W, v = ((float)y + dv) / (float)H;
     float st, ct, s2, c2;
     sincos_2pi(v * 0.5f, st, ct);
     sincos_2pi(u, s2, c2);
     dir = v3((-c2) * st, ct, (-s2) * st);
-    rad = sky_eval(sc, u, v);
-    pdf = st > 0.0f ? sc.pdf_uv[(size_t)y * W + x] / (2.0f * kPi * kPi * st) : 0.0f;
+    float pt;
+    rad = sky_eval_pdf(sc, u, v, (int)x, (int)y, pt);
+    pdf = st > 0.0f ? pt / (2.0f * kPi * kPi * st) : 0.0f;
 }
 
 // ------------------------------------------------------------------------------------------------ intersection (north_star)
@@ -552,6 +601,15 @@ RT3_DEV bool slab_test_hw(V3 bmin, V3 bmax, V3 o, V3 inv, float tmin, float tbes
     float ax = (bmin.x - o.x) * inv.x, bx = (bmax.x - o.x) * inv.x;
     float ay = (bmin.y - o.y) * inv.y, by = (bmax.y - o.y) * inv.y;
     float az = (bmin.z - o.z) * inv.z, bz = (bmax.z - o.z) * inv.z;
+    float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), tmin));
+    float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), tbest));
+    tn_out = tn;
+    return tn <= tf;
+}
+
+// slab test on ray parameters that are already computed (quantised nodes: t = fma(q, step*inv, (org-o)*inv)); arguments are
+// (lo, hi) per axis in x, y, z order
+RT3_DEV bool slab_test_q(float ax, float bx, float ay, float by, float az, float bz, float tmin, float tbest, float& tn_out) {
     float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), tmin));
     float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), tbest));
     tn_out = tn;

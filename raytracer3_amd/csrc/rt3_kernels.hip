@@ -89,7 +89,8 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
                                              const float* __restrict__ rays, size_t stride, uint32_t n, uint32_t* __restrict__ work_counter,
                                              uint32_t* __restrict__ lds, Finish finish) {
     constexpr bool WIDE = LAYOUT == kLayoutWide128;   // 8 x 16 B per fetch
-    constexpr bool WIDEQ = LAYOUT == kLayoutWide64Q;  // 4 x 16 B per fetch, quantised boxes
+    constexpr bool WIDEQ = LAYOUT == kLayoutWide64Q || LAYOUT == kLayoutWide48Q;  // quantised boxes
+    constexpr bool C48 = LAYOUT == kLayoutWide48Q;  // 3 x 16 B per fetch: node and triangle records are both 48 B
     // ray pool: waves grab chunks of kPoolChunk consecutive rays from a per-launch counter (one returning atomic per
     // chunk: ~110 k per launch, ~20 / us, below the ~88 / us a single counter word sustains; 64-ray chunks were
     // atomic-bound, 1024 and more left a visible tail), so no wave idles at the end of a
@@ -150,9 +151,9 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
         // ---- one traversal step
         const bool is_leaf = (r.cur & 0x80000000u) != 0u;
         const uint32_t first = r.cur & 0x0FFFFFFFu, cnt = ((r.cur >> 28) & 7u) + 1u;
-        const float4* p = is_leaf ? tris + 3 * (size_t)(first + r.leaf_k) : nodes + (WIDE ? 8 : 4) * (size_t)r.cur;
+        const float4* p = is_leaf ? tris + 3 * (size_t)(first + r.leaf_k) : nodes + (WIDE ? 8 : (C48 ? kC48Stride : 4)) * (size_t)r.cur;
         // one batch of loads (the triangle array carries 128 B of slack so that over-reading a leaf is in bounds)
-        float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3], q4, q5, q6, q7;
+        float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = C48 ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : p[3], q4, q5, q6, q7;
         if (WIDE) {
             q4 = p[4];
             q5 = p[5];
@@ -161,7 +162,8 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
         }
         // pin the fetched registers: without this LLVM sinks the loads only one branch needs into that branch, which
         // turns one memory round trip per step into two
-        pin(q0); pin(q1); pin(q2); pin(q3);
+        pin(q0); pin(q1); pin(q2);
+        if (!C48) pin(q3);
         if (WIDE) { pin(q4); pin(q5); pin(q6); pin(q7); }
         bool pop = false, done = false;
         const V3 o = r.o, d = r.d, inv = r.inv;
@@ -190,25 +192,48 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
                 uint32_t r0, r1, r2, r3;
                 bool h0, h1, h2, h3;
                 if (WIDEQ) {
-                    // decode: box = origin + float(q) * 2^(e-127); bytes 6k..6k+5 of words 4..9 hold child k
-                    const V3 org = v3(q0.x, q0.y, q0.z);
+                    // the dequantisation is folded into the ray: a child plane sits at org + q * 2^(e-127), so its ray parameter is
+                    // q * (step * inv) + (org - o) * inv = fma(q, A, B): one v_cvt_f32_ubyte + one v_fma_f32 per plane.
+                    // Bytes 6k..6k+5 of words 4..9 hold child k {lo.xyz, hi.xyz}.
                     const uint32_t ex = __float_as_uint(q0.w);
-                    const V3 sc = v3(__uint_as_float((ex & 0xFFu) << 23), __uint_as_float(((ex >> 8) & 0xFFu) << 23), __uint_as_float(((ex >> 16) & 0xFFu) << 23));
+                    const V3 A = v3(__uint_as_float((ex & 0xFFu) << 23) * inv.x, __uint_as_float(((ex >> 8) & 0xFFu) << 23) * inv.y,
+                                    __uint_as_float(((ex >> 16) & 0xFFu) << 23) * inv.z);
+                    const V3 B = v3((q0.x - o.x) * inv.x, (q0.y - o.y) * inv.y, (q0.z - o.z) * inv.z);
                     const uint32_t w0 = __float_as_uint(q1.x), w1 = __float_as_uint(q1.y), w2 = __float_as_uint(q1.z), w3 = __float_as_uint(q1.w),
                                    w4 = __float_as_uint(q2.x), w5 = __float_as_uint(q2.y);
-                    r0 = __float_as_uint(q2.z);
-                    r1 = __float_as_uint(q2.w);
-                    r2 = __float_as_uint(q3.x);
-                    r3 = __float_as_uint(q3.y);
+                    if (C48) {
+                        // implied references: internal children count up from node_base, leaf triangles from tri_base
+                        const uint32_t wa = __float_as_uint(q2.z), wb = __float_as_uint(q2.w);
+                        const uint32_t m0 = (ex >> 24) & 15u, m1 = ex >> 28, m2 = wa >> 28, m3 = wb >> 28;
+                        uint32_t nb = wa & 0x0FFFFFFFu, tb = wb & 0x0FFFFFFFu;
+#define RT3_REF48(m, out)                                                         \
+    {                                                                             \
+        const bool in_ = (m) == 0u, lf_ = ((m)&8u) != 0u;                         \
+        out = in_ ? nb : (lf_ ? (0x80000000u | (((m)&7u) << 28) | tb) : kEmptySlot); \
+        nb += in_ ? 1u : 0u;                                                      \
+        tb += lf_ ? ((m)&7u) + 1u : 0u;                                           \
+    }
+                        RT3_REF48(m0, r0)
+                        RT3_REF48(m1, r1)
+                        RT3_REF48(m2, r2)
+                        RT3_REF48(m3, r3)
+#undef RT3_REF48
+                    } else {
+                        r0 = __float_as_uint(q2.z);
+                        r1 = __float_as_uint(q2.w);
+                        r2 = __float_as_uint(q3.x);
+                        r3 = __float_as_uint(q3.y);
+                    }
 #define RT3_Q(w, b) ((float)(((w) >> (8 * (b))) & 0xFFu))
-#define RT3_DEQ(lx, ly, lz, hx, hy, hz) \
-    v3(org.x + (lx) * sc.x, org.y + (ly) * sc.y, org.z + (lz) * sc.z), v3(org.x + (hx) * sc.x, org.y + (hy) * sc.y, org.z + (hz) * sc.z)
-                    h0 = slab_test_hw(RT3_DEQ(RT3_Q(w0, 0), RT3_Q(w0, 1), RT3_Q(w0, 2), RT3_Q(w0, 3), RT3_Q(w1, 0), RT3_Q(w1, 1)), o, inv, tmin, r.best.t, t0) & (r0 != kEmptySlot);
-                    h1 = slab_test_hw(RT3_DEQ(RT3_Q(w1, 2), RT3_Q(w1, 3), RT3_Q(w2, 0), RT3_Q(w2, 1), RT3_Q(w2, 2), RT3_Q(w2, 3)), o, inv, tmin, r.best.t, t1) & (r1 != kEmptySlot);
-                    h2 = slab_test_hw(RT3_DEQ(RT3_Q(w3, 0), RT3_Q(w3, 1), RT3_Q(w3, 2), RT3_Q(w3, 3), RT3_Q(w4, 0), RT3_Q(w4, 1)), o, inv, tmin, r.best.t, t2) & (r2 != kEmptySlot);
-                    h3 = slab_test_hw(RT3_DEQ(RT3_Q(w4, 2), RT3_Q(w4, 3), RT3_Q(w5, 0), RT3_Q(w5, 1), RT3_Q(w5, 2), RT3_Q(w5, 3)), o, inv, tmin, r.best.t, t3) & (r3 != kEmptySlot);
+#define RT3_SLABQ(lx, ly, lz, hx, hy, hz, tn) \
+    slab_test_q(__builtin_fmaf(lx, A.x, B.x), __builtin_fmaf(hx, A.x, B.x), __builtin_fmaf(ly, A.y, B.y), __builtin_fmaf(hy, A.y, B.y), \
+                __builtin_fmaf(lz, A.z, B.z), __builtin_fmaf(hz, A.z, B.z), tmin, r.best.t, tn)
+                    h0 = RT3_SLABQ(RT3_Q(w0, 0), RT3_Q(w0, 1), RT3_Q(w0, 2), RT3_Q(w0, 3), RT3_Q(w1, 0), RT3_Q(w1, 1), t0) & (r0 != kEmptySlot);
+                    h1 = RT3_SLABQ(RT3_Q(w1, 2), RT3_Q(w1, 3), RT3_Q(w2, 0), RT3_Q(w2, 1), RT3_Q(w2, 2), RT3_Q(w2, 3), t1) & (r1 != kEmptySlot);
+                    h2 = RT3_SLABQ(RT3_Q(w3, 0), RT3_Q(w3, 1), RT3_Q(w3, 2), RT3_Q(w3, 3), RT3_Q(w4, 0), RT3_Q(w4, 1), t2) & (r2 != kEmptySlot);
+                    h3 = RT3_SLABQ(RT3_Q(w4, 2), RT3_Q(w4, 3), RT3_Q(w5, 0), RT3_Q(w5, 1), RT3_Q(w5, 2), RT3_Q(w5, 3), t3) & (r3 != kEmptySlot);
 #undef RT3_Q
-#undef RT3_DEQ
+#undef RT3_SLABQ
                 } else {
                     r0 = __float_as_uint(q1.z);
                     r1 = __float_as_uint(q3.z);
@@ -435,6 +460,7 @@ struct ShadeArgs {
     SceneDev sc;
     const uint32_t* pixels;  // x | y << 16, this rank's pixels in render order
     uint32_t npix, width;
+    FastDiv npix_div;        // path id = sample_in_batch * npix + pixel_index
     uint32_t s0;             // first sample index of this batch
     uint32_t bounce;         // b
     // FIRST: gbuffer images
@@ -483,10 +509,11 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
         surf.normal = v3(0, 0, 1);
         surf.roughness = 1.0f;
         surf.metalness = 0.0f;
-        uint32_t px = 0, py = 0;
+        uint32_t px = 0, py = 0, sample_in_batch = 0;
         if (active) {
             pid = FIRST ? i : a.in_pid[i];
-            uint32_t xy = a.pixels[pid % a.npix];
+            sample_in_batch = fast_div(a.npix_div, pid);
+            uint32_t xy = a.pixels[pid - sample_in_batch * a.npix];
             px = xy & 0xFFFFu;
             py = xy >> 16;
         }
@@ -516,8 +543,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
                 if (nee && pdf_b > 0.0f) {
                     float su, sv;
                     direction_to_equirect_uv(d, su, sv);
-                    V3 rad = sky_eval(a.sc, su, sv);
-                    float pl = sky_pdf(a.sc, su, sv);
+                    float pl;
+                    V3 rad = sky_eval_and_pdf(a.sc, su, sv, pl);
                     float w = pdf_b / (pdf_b + pl);
                     float4* Lp = reinterpret_cast<float4*>(a.lacc) + pid;
                     float4 lv = *Lp;
@@ -534,12 +561,13 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
         float pdf_n = 0.0f;
         if (active) {
             uint32_t seed = rng_seed(px, py, g.frame);  // :25
-            uint32_t sm = a.s0 + pid / a.npix;
+            uint32_t sm = a.s0 + sample_in_batch;
             uint32_t base = (sm * B + b) * dims;
             float u0 = uniform_float(seed, base), u1 = uniform_float(seed, base + 1);  // :43
             uint32_t bn = 0;
             if (bnz) {
-                bn = *reinterpret_cast<const uint32_t*>(a.sc.bluenoise + 4 * ((size_t)(py % a.sc.bn_h) * a.sc.bn_w + (px % a.sc.bn_w)));
+                const uint32_t by = py - fast_div(a.sc.bn_h_div, py) * a.sc.bn_h, bx = px - fast_div(a.sc.bn_w_div, px) * a.sc.bn_w;  // py % bn_h, px % bn_w
+                bn = *reinterpret_cast<const uint32_t*>(a.sc.bluenoise + 4 * ((size_t)by * a.sc.bn_w + bx));
                 u0 = bluenoise_shift(u0, bn & 0xFFu);
                 u1 = bluenoise_shift(u1, (bn >> 8) & 0xFFu);
             }
@@ -782,12 +810,21 @@ __global__ void k_selftest(int op, const uint32_t* __restrict__ in, uint32_t n, 
         }
         case 10: out[i] = U(atan2_poly(F(in[2 * i]), F(in[2 * i + 1]))); break;
         case 11: out[i] = rng_seed(in[3 * i], in[3 * i + 1], in[3 * i + 2]); break;
+        case 12: {  // the division-free n / d and wrap used by k_shade: {n / d, n % d, wrap_index((int)n, (int)d)}
+            const uint32_t nn = in[2 * i], dd = in[2 * i + 1];
+            const FastDiv f = make_fastdiv(dd);
+            const uint32_t q = fast_div(f, nn);
+            out[3 * i] = q;
+            out[3 * i + 1] = nn - q * dd;
+            out[3 * i + 2] = (uint32_t)wrap_index((int)nn, (int)(dd & 0xFFFFu) + 1);
+            break;
+        }
         default: break;
     }
 }
 bool selftest_widths(int op, uint32_t* in_w, uint32_t* out_w) {
-    static const uint32_t w[12][2] = {{1, 1}, {2, 1}, {2, 1}, {2, 1}, {11, 4}, {4, 11}, {2, 3}, {3, 6}, {3, 3}, {1, 2}, {2, 1}, {3, 1}};
-    if (op < 0 || op > 11) return false;
+    static const uint32_t w[13][2] = {{1, 1}, {2, 1}, {2, 1}, {2, 1}, {11, 4}, {4, 11}, {2, 3}, {3, 6}, {3, 3}, {1, 2}, {2, 1}, {3, 1}, {2, 3}};
+    if (op < 0 || op > 12) return false;
     *in_w = w[op][0];
     *out_w = w[op][1];
     return true;
@@ -814,11 +851,13 @@ void launch_extend(hipStream_t st, bool count, int layout, const float4* nodes, 
     hipLaunchKernelGGL((k_extend<C, L>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, hits, cn, ct, totals, \
                        work_counter)
     if (count) {
-        if (layout == kLayoutWide64Q) RT3_LAUNCH_EXTEND(true, kLayoutWide64Q);
+        if (layout == kLayoutWide48Q) RT3_LAUNCH_EXTEND(true, kLayoutWide48Q);
+        else if (layout == kLayoutWide64Q) RT3_LAUNCH_EXTEND(true, kLayoutWide64Q);
         else if (layout == kLayoutWide128) RT3_LAUNCH_EXTEND(true, kLayoutWide128);
         else RT3_LAUNCH_EXTEND(true, kLayoutBinary64);
     } else {
-        if (layout == kLayoutWide64Q) RT3_LAUNCH_EXTEND(false, kLayoutWide64Q);
+        if (layout == kLayoutWide48Q) RT3_LAUNCH_EXTEND(false, kLayoutWide48Q);
+        else if (layout == kLayoutWide64Q) RT3_LAUNCH_EXTEND(false, kLayoutWide64Q);
         else if (layout == kLayoutWide128) RT3_LAUNCH_EXTEND(false, kLayoutWide128);
         else RT3_LAUNCH_EXTEND(false, kLayoutBinary64);
     }
@@ -832,11 +871,13 @@ void launch_shadow(hipStream_t st, bool count, int layout, const float4* nodes, 
     hipLaunchKernelGGL((k_shadow<C, L>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, contrib, pid, lacc, \
                        lstride, occluded_out, cn, ct, totals, work_counter)
     if (count) {
-        if (layout == kLayoutWide64Q) RT3_LAUNCH_SHADOW(true, kLayoutWide64Q);
+        if (layout == kLayoutWide48Q) RT3_LAUNCH_SHADOW(true, kLayoutWide48Q);
+        else if (layout == kLayoutWide64Q) RT3_LAUNCH_SHADOW(true, kLayoutWide64Q);
         else if (layout == kLayoutWide128) RT3_LAUNCH_SHADOW(true, kLayoutWide128);
         else RT3_LAUNCH_SHADOW(true, kLayoutBinary64);
     } else {
-        if (layout == kLayoutWide64Q) RT3_LAUNCH_SHADOW(false, kLayoutWide64Q);
+        if (layout == kLayoutWide48Q) RT3_LAUNCH_SHADOW(false, kLayoutWide48Q);
+        else if (layout == kLayoutWide64Q) RT3_LAUNCH_SHADOW(false, kLayoutWide64Q);
         else if (layout == kLayoutWide128) RT3_LAUNCH_SHADOW(false, kLayoutWide128);
         else RT3_LAUNCH_SHADOW(false, kLayoutBinary64);
     }
@@ -849,6 +890,7 @@ void launch_gbuffer(hipStream_t st, const SceneDev& sc, const uint32_t* pixels, 
 void launch_shade(hipStream_t st, bool first, const ShadeLaunch& L) {
     ShadeArgs a;
     a.g = L.g; a.sc = L.sc; a.pixels = L.pixels; a.npix = L.npix; a.width = L.width; a.s0 = L.s0; a.bounce = L.bounce;
+    a.npix_div = make_fastdiv(L.npix);
     a.gbuffer = (const uint4*)L.gbuffer; a.depth = L.depth;
     a.in_rays = L.in_rays; a.in_hits = L.in_hits; a.in_T = L.in_T; a.in_pid = L.in_pid; a.in_count = L.in_count; a.n_first = L.n_first;
     a.out_rays = L.out_rays; a.out_T = L.out_T; a.out_pid = L.out_pid; a.out_count = L.out_count;

@@ -287,8 +287,7 @@ __device__ __forceinline__ void slot_of(uint32_t ch, const float* lmin, const fl
 //   float4 0: origin.xyz, exponents ex | ey << 8 | ez << 16      float4 1 + first half of 2: 4 x {qlo.xyz, qhi.xyz} bytes
 //   float4 2 second half + float4 3 first half: the four references
 // Conservative with respect to the decode expression origin + float(q) * scale used by the traversal kernels.
-__device__ void quantize_node(const float (*mn)[3], const float (*mx)[3], const uint32_t* ref, uint32_t ns, float4* out) {
-    uint32_t w[16];
+__device__ void quantize_words(const float (*mn)[3], const float (*mx)[3], const uint32_t* ref, uint32_t ns, uint32_t* w) {
 #pragma unroll
     for (int k = 0; k < 16; k++) w[k] = 0u;
     uint32_t qb[4][6];
@@ -330,15 +329,90 @@ __device__ void quantize_node(const float (*mn)[3], const float (*mx)[3], const 
         }
         w[10 + k] = k < ns ? ref[k] : 0xFFFFFFFFu;
     }
+}
+__device__ void quantize_node(const float (*mn)[3], const float (*mx)[3], const uint32_t* ref, uint32_t ns, float4* out) {
+    uint32_t w[16];
+    quantize_words(mn, mx, ref, ns, w);
 #pragma unroll
     for (int k = 0; k < 4; k++)
         out[k] = make_float4(__uint_as_float(w[4 * k]), __uint_as_float(w[4 * k + 1]), __uint_as_float(w[4 * k + 2]), __uint_as_float(w[4 * k + 3]));
+}
+// compact 48-byte node: words 0..9 as above; the references are implied -- internal children are numbered consecutively
+// from node_base, the triangles of leaf children are stored consecutively from tri_base (slot order), and one nibble
+// per child says what it is: 0 internal, 8 | (count - 1) leaf, 7 empty.  Nibbles 0,1 -> bits 24..31 of word 3,
+// nibble 2 / 3 -> top of word 10 (node_base) / word 11 (tri_base).
+__device__ void compact_node(const float (*mn)[3], const float (*mx)[3], const uint32_t* meta, uint32_t ns, uint32_t node_base, uint32_t tri_base,
+                             float4* out) {
+    uint32_t w[16];
+    const uint32_t zero[4] = {0, 0, 0, 0};
+    quantize_words(mn, mx, zero, ns, w);
+    uint32_t m[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) m[k] = k < ns ? meta[k] : 7u;
+    w[3] |= (m[0] << 24) | (m[1] << 28);
+    w[10] = (node_base & 0x0FFFFFFFu) | (m[2] << 28);
+    w[11] = (tri_base & 0x0FFFFFFFu) | (m[3] << 28);
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        out[k] = make_float4(__uint_as_float(w[4 * k]), __uint_as_float(w[4 * k + 1]), __uint_as_float(w[4 * k + 2]), __uint_as_float(w[4 * k + 3]));
+}
+
+// child slots of surviving node i, in tree order: with four-wide nodes a child that is itself a live internal node is
+// absorbed (its two children take its place)
+__device__ __forceinline__ uint32_t gather_slots(uint32_t i, const uint32_t* left, const uint32_t* right, const uint32_t* range_cnt,
+                                                 uint32_t leaf_max, int wide, uint32_t sl[4]) {
+    uint32_t ns = 0;
+    const uint32_t c2[2] = {left[i], right[i]};
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const uint32_t ch = c2[c];
+        if (wide && !(ch & 0x80000000u) && range_cnt[ch] > leaf_max) {
+            sl[ns++] = left[ch];
+            sl[ns++] = right[ch];
+        } else {
+            sl[ns++] = ch;
+        }
+    }
+    for (uint32_t k = ns; k < 4; k++) sl[k] = 0xFFFFFFFFu;
+    return ns;
+}
+
+// compact layout, pass 1: per surviving node the number of internal child slots and of triangles in leaf slots
+__global__ void k_child_counts(const uint32_t* left, const uint32_t* right, const uint32_t* range_cnt, const uint32_t* keep, uint32_t nn,
+                               uint32_t leaf_max, uint32_t* n_internal, uint32_t* n_leaf_tris) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += gridDim.x * blockDim.x) {
+        uint32_t ci = 0, ti = 0;
+        if (keep[i]) {
+            uint32_t sl[4];
+            const uint32_t ns = gather_slots(i, left, right, range_cnt, leaf_max, 1, sl);
+            for (uint32_t k = 0; k < ns; k++) {
+                if (sl[k] & 0x80000000u) ti += 1u;
+                else if (range_cnt[sl[k]] > leaf_max) ci += 1u;
+                else ti += range_cnt[sl[k]];
+            }
+        }
+        n_internal[i] = ci;
+        n_leaf_tris[i] = ti;
+    }
+}
+// compact layout, pass 2 (after the exclusive sums): a child's index is 1 + node_base(parent) + rank among the internal slots
+__global__ void k_assign_index(const uint32_t* left, const uint32_t* right, const uint32_t* range_cnt, const uint32_t* keep, uint32_t nn,
+                               uint32_t leaf_max, const uint32_t* cbase, uint32_t* newidx) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += gridDim.x * blockDim.x) {
+        if (i == 0) newidx[0] = 0u;
+        if (!keep[i]) continue;
+        uint32_t sl[4], rank = 0;
+        const uint32_t ns = gather_slots(i, left, right, range_cnt, leaf_max, 1, sl);
+        for (uint32_t k = 0; k < ns; k++)
+            if (!(sl[k] & 0x80000000u) && range_cnt[sl[k]] > leaf_max) newidx[sl[k]] = 1u + cbase[i] + rank++;
+    }
 }
 
 // one thread per surviving node: gather its 2 (binary) or 2..4 (wide: internal children are absorbed) child slots
 __global__ void k_emit_nodes(const uint32_t* left, const uint32_t* right, const uint32_t* range_lo, const uint32_t* range_cnt,
                              const uint32_t* keep, const uint32_t* newidx, const float* lmin, const float* lmax, const float* nbox,
-                             uint32_t nn, uint32_t leaf_max, int wide, int quant, float4* nodes) {
+                             uint32_t nn, uint32_t leaf_max, int wide, int quant, float4* nodes, const uint32_t* cbase, const uint32_t* tbase,
+                             const float4* tris_morton, float4* tris_out) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += gridDim.x * blockDim.x) {
         if (!keep[i]) continue;
         uint32_t s0 = left[i], s1 = right[i], s2 = 0xFFFFFFFFu, s3 = 0xFFFFFFFFu;
@@ -366,7 +440,22 @@ __global__ void k_emit_nodes(const uint32_t* left, const uint32_t* right, const 
             float qmn[4][3], qmx[4][3];
             uint32_t qref[4] = {0, 0, 0, 0};
             for (uint32_t k = 0; k < ns; k++) slot_of(sl[k], lmin, lmax, nbox, range_lo, range_cnt, newidx, leaf_max, qmn[k], qmx[k], qref[k]);
-            quantize_node(qmn, qmx, qref, ns, nodes + 4 * (size_t)o);
+            if (quant == 2) {
+                uint32_t meta[4] = {7u, 7u, 7u, 7u}, tcur = tbase[i];
+                for (uint32_t k = 0; k < ns; k++) {
+                    if (qref[k] & 0x80000000u) {  // move the leaf's triangles to their place behind tri_base
+                        const uint32_t first = qref[k] & 0x0FFFFFFFu, cnt = ((qref[k] >> 28) & 7u) + 1u;
+                        meta[k] = 8u | (cnt - 1u);
+                        for (uint32_t t = 0; t < 3u * cnt; t++) tris_out[3 * (size_t)tcur + t] = tris_morton[3 * (size_t)first + t];
+                        tcur += cnt;
+                    } else {
+                        meta[k] = 0u;
+                    }
+                }
+                compact_node(qmn, qmx, meta, ns, 1u + cbase[i], tbase[i], nodes + kC48Stride * (size_t)o);
+            } else {
+                quantize_node(qmn, qmx, qref, ns, nodes + 4 * (size_t)o);
+            }
         } else if (wide) {
             const float inf = INFINITY;
             const uint32_t sl[4] = {s0, s1, s2, s3};
@@ -406,7 +495,9 @@ __global__ void k_single(const float* lmin, const float* lmax, int wide, int qua
             qmn[0][j] = lmin[j];
             qmx[0][j] = lmax[j];
         }
-        quantize_node(qmn, qmx, qref, 1, nodes);
+        const uint32_t qmeta[4] = {8u, 7u, 7u, 7u};
+        if (quant == 2) compact_node(qmn, qmx, qmeta, 1, 1u, 0u, nodes);
+        else quantize_node(qmn, qmx, qref, 1, nodes);
     } else if (wide) {
         nodes[0] = make_float4(lmin[0], lmin[1], lmin[2], lmax[0]);
         nodes[1] = make_float4(lmax[1], lmax[2], __uint_as_float(0x80000000u), 0.0f);
@@ -436,14 +527,16 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
     hipError_t err = hipSuccess;
     *out = LbvhResult{};
     out->n_tris = n;
-    const int wide = node_width == 4, quant = wide && node_quant;
-    out->node_bytes = (wide && !quant) ? 128u : 64u;
-    out->layout = !wide ? kLayoutBinary64 : (quant ? kLayoutWide64Q : kLayoutWide128);
+    const int wide = node_width == 4, quant = wide ? (node_quant > 2 ? 2 : (int)node_quant) : 0;
+    out->node_bytes = (wide && !quant) ? 128u : (quant == 2 ? 16u * kC48Stride : 64u);
+    out->layout = !wide ? kLayoutBinary64 : (quant == 2 ? kLayoutWide48Q : (quant ? kLayoutWide64Q : kLayoutWide128));
     if (n == 0) return hipSuccess;
     const uint32_t nn = n > 1 ? n - 1 : 1;
     float *bmin = nullptr, *bmax = nullptr, *lmin = nullptr, *lmax = nullptr, *nbox = nullptr;
     uint32_t *bounds = nullptr, *vals_in = nullptr, *vals_out = nullptr, *left = nullptr, *right = nullptr, *pint = nullptr, *pleaf = nullptr,
-             *arrive = nullptr, *levels = nullptr, *rlo = nullptr, *rcnt = nullptr, *keep = nullptr, *newidx = nullptr;
+             *arrive = nullptr, *levels = nullptr, *rlo = nullptr, *rcnt = nullptr, *keep = nullptr, *newidx = nullptr, *n_int = nullptr,
+             *n_ltri = nullptr, *cbase = nullptr, *tbase = nullptr;
+    float4* tris_morton = nullptr;  // compact layout: Morton-ordered triangle records before they move into leaf order
     uint64_t *keys_in = nullptr, *keys_out = nullptr;
     void *temp = nullptr, *temp2 = nullptr;
     size_t temp_bytes = 0, temp2_bytes = 0;
@@ -479,6 +572,13 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
     LB_CHECK(hipMalloc(&out->tris, (size_t)n * 48 + 128));  // + slack: the traversal fetch may over-read the last leaf by up to 128 B
     LB_CHECK(hipMemsetAsync((char*)out->tris + (size_t)n * 48, 0, 128, st));
     LB_CHECK(hipMalloc(&out->tri_shade, (size_t)n * 64));
+    if (quant == 2 && n > 1) {
+        LB_CHECK(hipMalloc(&tris_morton, (size_t)n * 48));
+        LB_CHECK(hipMalloc(&n_int, (size_t)nn * 4));
+        LB_CHECK(hipMalloc(&n_ltri, (size_t)nn * 4));
+        LB_CHECK(hipMalloc(&cbase, (size_t)nn * 4));
+        LB_CHECK(hipMalloc(&tbase, (size_t)nn * 4));
+    }
     LB_CHECK(hipMemcpyAsync(bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, st));
     LB_CHECK(hipMemsetAsync(arrive, 0, (size_t)nn * 4, st));
     LB_CHECK(hipMemsetAsync(levels, 0, 4, st));
@@ -489,7 +589,7 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
     LB_CHECK(hipMalloc(&temp, temp_bytes ? temp_bytes : 16));
     LB_CHECK(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, 63, st));
     hipLaunchKernelGGL(k_leaves, dim3(grid), dim3(256), 0, st, verts, indices, geoms, prim_geom, first_prim, vals_out, bmin, bmax, bounds, n,
-                       out->tris, lmin, lmax);
+                       tris_morton ? tris_morton : out->tris, lmin, lmax);
     if (n == 1) {
         LB_CHECK(hipMalloc(&out->nodes, out->node_bytes));
         hipLaunchKernelGGL(k_single, dim3(1), dim3(1), 0, st, lmin, lmax, wide, quant, out->nodes);
@@ -510,15 +610,21 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
         LB_CHECK(hipStreamSynchronize(st));
         out->n_nodes = tail[0] + tail[1];
         LB_CHECK(hipMalloc(&out->nodes, (size_t)out->n_nodes * out->node_bytes));
+        if (quant == 2) {
+            hipLaunchKernelGGL(k_child_counts, dim3(grid), dim3(256), 0, st, left, right, rcnt, keep, nn, leaf_max, n_int, n_ltri);
+            LB_CHECK(hipcub::DeviceScan::ExclusiveSum(temp2, temp2_bytes, n_int, cbase, (int)nn, st));
+            LB_CHECK(hipcub::DeviceScan::ExclusiveSum(temp2, temp2_bytes, n_ltri, tbase, (int)nn, st));
+            hipLaunchKernelGGL(k_assign_index, dim3(grid), dim3(256), 0, st, left, right, rcnt, keep, nn, leaf_max, cbase, newidx);
+        }
         hipLaunchKernelGGL(k_emit_nodes, dim3(grid), dim3(256), 0, st, left, right, rlo, rcnt, keep, newidx, lmin, lmax, nbox, nn, leaf_max, wide,
-                           quant, out->nodes);
+                           quant, out->nodes, cbase, tbase, tris_morton, out->tris);
         LB_CHECK(hipGetLastError());
         LB_CHECK(hipStreamSynchronize(st));
     }
 done:
     for (void* p : {(void*)bmin, (void*)bmax, (void*)lmin, (void*)lmax, (void*)nbox, (void*)bounds, (void*)keys_in, (void*)keys_out, (void*)vals_in,
                     (void*)vals_out, (void*)left, (void*)right, (void*)pint, (void*)pleaf, (void*)arrive, (void*)levels, (void*)rlo, (void*)rcnt,
-                    (void*)keep, (void*)newidx, temp, temp2})
+                    (void*)keep, (void*)newidx, (void*)n_int, (void*)n_ltri, (void*)cbase, (void*)tbase, (void*)tris_morton, temp, temp2})
         (void)hipFree(p);
     if (err != hipSuccess) {
         (void)hipFree(out->nodes);

@@ -121,6 +121,21 @@ def test_gpu_device_functions_known_answers():
     assert np.array_equal(ctx.selftest(2, seeds, 1).reshape(-1, 8), z["rng_out"])
     assert np.array_equal(ctx.selftest(4, z["surf"].view(np.uint32), 4), z["packed"])
     assert np.array_equal(ctx.selftest(5, z["packed"], 11), z["unpacked"].view(np.uint32))
+    # division-free integer helpers of k_shade (magic-number divide, conditional wrap) against Python's exact integers
+    rng = np.random.default_rng(11)
+    nd = np.stack([rng.integers(0, 2**32, 4096, dtype=np.uint64), rng.integers(1, 2**32, 4096, dtype=np.uint64)], 1)
+    nd[:64, 1] = np.arange(1, 65)
+    nd[64:128, 1] = 2 ** rng.integers(0, 32, 64)
+    nd[128:192, 0] = 0xFFFFFFFF - np.arange(64)
+    nd[192:256, 1] = 0xFFFFFFFF - np.arange(64)
+    nd[256:320] = [[1920 * 1080 * 16 - 1 - k, 1920 * 1080] for k in range(64)]
+    got = ctx.selftest(12, nd.astype(np.uint32), 3)
+    assert np.array_equal(got[:, 0], (nd[:, 0] // nd[:, 1]).astype(np.uint32)) and np.array_equal(got[:, 1], (nd[:, 0] % nd[:, 1]).astype(np.uint32))
+    xs = nd[:, 0].astype(np.uint32).view(np.int32).astype(np.int64)
+    xs[:2048] = rng.integers(-70000, 140000, 2048)
+    ws = (nd[:, 1] & 0xFFFF).astype(np.int64) + 1
+    nd2 = np.stack([xs.astype(np.int32).view(np.uint32), nd[:, 1].astype(np.uint32)], 1)
+    assert np.array_equal(ctx.selftest(12, nd2, 3)[:, 2].astype(np.int64), np.mod(xs, ws))
     assert np.array_equal(ctx.selftest(6, z["urand"].view(np.uint32), 3), z["diffuse_wi"].view(np.uint32))
     assert np.array_equal(ctx.selftest(7, z["normals"].view(np.uint32), 6), z["onb"].view(np.uint32))
     agx_in = np.stack([z["agx_in"], z["agx_in"] * np.float32(0.5), z["agx_in"] * np.float32(0.25)], 1).astype(np.float32)

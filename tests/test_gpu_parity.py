@@ -55,9 +55,9 @@ def test_device_is_gfx950():
     ctx.close()
 
 
-@pytest.mark.parametrize("leaf,width,quant", [(2, 4, 1), (2, 4, 0), (1, 2, 0), (4, 4, 1), (8, 4, 0), (4, 2, 0), (1, 4, 1)])
+@pytest.mark.parametrize("leaf,width,quant", [(2, 4, 2), (2, 4, 1), (2, 4, 0), (1, 2, 0), (4, 4, 1), (8, 4, 0), (4, 2, 0), (1, 4, 1), (1, 4, 2), (8, 4, 2)])
 def test_lbvh_bit_identical_to_oracle(small, leaf, width, quant):
-    """every layout: 64 B binary / 128 B four-wide / 64 B quantised four-wide nodes x 1..8 triangles per leaf"""
+    """every layout: 64 B binary / 128 B four-wide / 64 B quantised / 48 B compact four-wide nodes x 1..8 triangles per leaf"""
     mesh, sky, bn, _ = small
     osc = orc.Scene(mesh, leaf_size=leaf, node_width=width, quantized=quant)
     ctx = Context(0)
@@ -68,7 +68,7 @@ def test_lbvh_bit_identical_to_oracle(small, leaf, width, quant):
     handle = ctx.build_accel()
     assert handle >> 30 == L.TAG_ACCEL
     nn, nt, levels, nb = ctx.accel_info()
-    assert (nn, nt, levels, nb) == (osc.n_nodes, osc.n_tris, osc.max_depth, 64 if (width == 2 or quant) else 128)
+    assert (nn, nt, levels, nb) == (osc.n_nodes, osc.n_tris, osc.max_depth, 64 if width == 2 else {0: 128, 1: 64, 2: 48}[quant])
     nodes, tris = ctx.accel_download()
     assert np.array_equal(tris, osc.tris())
     assert np.array_equal(nodes, osc.nodes())

@@ -35,7 +35,7 @@ def test_bvh_equals_bruteforce_fp32_and_tracks_fp64():
     occ = sc.trace_any(rays)
     assert np.array_equal(occ != 0, p != orc.MISS)
     # the layout (leaf size, node width) changes the walk, never the answer
-    for leaf, width, quant in ((1, 2, 0), (4, 2, 0), (1, 4, 0), (8, 4, 0), (2, 4, 0), (4, 4, 1)):
+    for leaf, width, quant in ((1, 2, 0), (4, 2, 0), (1, 4, 0), (8, 4, 0), (2, 4, 0), (4, 4, 1), (2, 4, 2), (1, 4, 2), (8, 4, 2)):
         alt = orc.Scene(mesh, leaf_size=leaf, node_width=width, quantized=quant)
         at, au, av, ap = alt.trace_closest(rays)
         assert np.array_equal(ap, p) and np.array_equal(at, t) and np.array_equal(au, u) and np.array_equal(av, v)
