@@ -895,20 +895,28 @@ typedef struct { float t, u, v; uint32_t prim; } hit_t;
 /* [north_star] Moeller-Trumbore on precomputed (v0,e1,e2); both faces hit (no cull flags: pipeline_cache/mod.rs:326-333
  * registers a plain closest-hit group).  Acceptance: t > tmin and (t < best.t or (t == best.t and prim < best.prim)),
  * which makes the closest hit independent of traversal order. */
+/* cross / dot products of the triangle test use fused multiply-adds in a fixed order (the GPU's v_fma_f32; here
+ * __builtin_fmaf, one vfmadd in the "fma" clones of the callers): x*y - z*w = fma(x, y, -(z*w)), a.b = fma(a0, b0, fma(a1, b1, a2*b2)) */
+static inline float dot3f(const float a[3], const float b[3]) { return __builtin_fmaf(a[0], b[0], __builtin_fmaf(a[1], b[1], a[2] * b[2])); }
+static inline void cross3f(const float a[3], const float b[3], float o[3]) {
+    o[0] = __builtin_fmaf(a[1], b[2], -(a[2] * b[1]));
+    o[1] = __builtin_fmaf(a[2], b[0], -(a[0] * b[2]));
+    o[2] = __builtin_fmaf(a[0], b[1], -(a[1] * b[0]));
+}
 static inline void tri_test(const float *tr, const float o[3], const float d[3], float tmin, hit_t *best) {
     const float *v0 = tr, *e1 = tr + 3, *e2 = tr + 6;
     float pv[3], tv[3], qv[3];
-    cross3(d, e2, pv);
-    float det = dot3(e1, pv);
+    cross3f(d, e2, pv);
+    float det = dot3f(e1, pv);
     if (det == 0.0f) return;
     float inv = 1.0f / det;
     tv[0] = o[0] - v0[0]; tv[1] = o[1] - v0[1]; tv[2] = o[2] - v0[2];
-    float u = dot3(tv, pv) * inv;
+    float u = dot3f(tv, pv) * inv;
     if (!(u >= 0.0f && u <= 1.0f)) return;
-    cross3(tv, e1, qv);
-    float v = dot3(d, qv) * inv;
+    cross3f(tv, e1, qv);
+    float v = dot3f(d, qv) * inv;
     if (!(v >= 0.0f && u + v <= 1.0f)) return;
-    float t = dot3(e2, qv) * inv;
+    float t = dot3f(e2, qv) * inv;
     uint32_t prim = f2u(tr[9]);
     if (t > tmin && (t < best->t || (t == best->t && prim < best->prim))) { best->t = t; best->u = u; best->v = v; best->prim = prim; }
 }
@@ -1076,6 +1084,7 @@ static void tri_test_f64(const float *tr, const float of[3], const float df[3], 
     uint32_t prim = f2u(tr[9]);
     if (t > tmin && (t < *bt || (t == *bt && prim < *bp))) { *bt = t; *bu = u; *bv = v; *bp = prim; }
 }
+__attribute__((target_clones("fma", "default")))
 static void trace_brute_body(void *c, uint32_t b, uint32_t e, int tid) {
     (void)tid;
     trace_job *j = (trace_job *)c; uint32_t n = j->n; const float *r = j->rays; const orc_scene *s = j->s;

@@ -546,26 +546,10 @@ struct Hit {
 };
 // Moeller-Trumbore on (v0, e1, e2); tri = 3 x float4: {v0.xyz,e1.x} {e1.yz,e2.xy} {e2.z,prim,-,-}.  Two-sided.
 // Order-independent acceptance: t > tmin && (t < best.t || (t == best.t && prim < best.prim)).
-RT3_DEV void tri_test(float4 q0, float4 q1, float4 q2, V3 o, V3 d, float tmin, Hit& best) {
-    V3 v0 = v3(q0.x, q0.y, q0.z), e1 = v3(q0.w, q1.x, q1.y), e2 = v3(q1.z, q1.w, q2.x);
-    V3 pv = cross(d, e2);
-    float det = dot(e1, pv);
-    if (det == 0.0f) return;
-    float inv = 1.0f / det;
-    V3 tv = o - v0;
-    float u = dot(tv, pv) * inv;
-    if (!(u >= 0.0f && u <= 1.0f)) return;
-    V3 qv = cross(tv, e1);
-    float v = dot(d, qv) * inv;
-    if (!(v >= 0.0f && u + v <= 1.0f)) return;
-    float t = dot(e2, qv) * inv;
-    uint32_t prim = __float_as_uint(q2.y);
-    if (t > tmin && (t < best.t || (t == best.t && prim < best.prim))) {
-        best.t = t;
-        best.u = u;
-        best.v = v;
-        best.prim = prim;
-    }
+// Cross / dot products use explicit fused multiply-adds in a fixed order (the oracle mirrors them with fmaf).
+RT3_DEV float dot_fma(V3 a, V3 b) { return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, a.z * b.z)); }
+RT3_DEV V3 cross_fma(V3 a, V3 b) {
+    return V3{__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)), __builtin_fmaf(a.x, b.y, -(a.y * b.x))};
 }
 RT3_DEV float guarded_inverse(float d) {
     float a = d < 0.0f ? -d : d;

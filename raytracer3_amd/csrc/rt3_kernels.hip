@@ -40,18 +40,18 @@ __device__ __forceinline__ void cswap(Cand& a, Cand& b) {
     b.ref = sw ? ra : b.ref;
 }
 __device__ __forceinline__ void pin(float4& q) { asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w)); }
-// branch-free form of tri_test (same arithmetic, same acceptance rule): no early-outs, so the three loads of a
+// branch-free Moeller-Trumbore (the oracle's tri_test arithmetic and acceptance rule): no early-outs, so the three loads of a
 // triangle are issued together instead of being sunk behind the det / u / v branches
 __device__ __forceinline__ void tri_test_nb(float4 q0, float4 q1, float4 q2, V3 o, V3 d, float tmin, Hit& best) {
     V3 v0 = v3(q0.x, q0.y, q0.z), e1 = v3(q0.w, q1.x, q1.y), e2 = v3(q1.z, q1.w, q2.x);
-    V3 pv = cross(d, e2);
-    float det = dot(e1, pv);
+    V3 pv = cross_fma(d, e2);
+    float det = dot_fma(e1, pv);
     float inv = 1.0f / det;
     V3 tv = o - v0;
-    float u = dot(tv, pv) * inv;
-    V3 qv = cross(tv, e1);
-    float v = dot(d, qv) * inv;
-    float t = dot(e2, qv) * inv;
+    float u = dot_fma(tv, pv) * inv;
+    V3 qv = cross_fma(tv, e1);
+    float v = dot_fma(d, qv) * inv;
+    float t = dot_fma(e2, qv) * inv;
     uint32_t prim = __float_as_uint(q2.y);
     bool ok = (det != 0.0f) & (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > tmin) &
               ((t < best.t) | ((t == best.t) & (prim < best.prim)));
