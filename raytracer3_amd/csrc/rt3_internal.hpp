@@ -24,7 +24,7 @@ constexpr int kLayoutWide48Q = 3;    // 48 B: as kLayoutWide64Q, references impl
 #endif
 constexpr int kC48Stride = RT3_C48_STRIDE;  // float4s between consecutive compact nodes (experiment: 4 = padded to 64 B)
 constexpr int kLayoutWide64Q = 2;    // 64 B: origin + power-of-two steps + four 8-bit boxes + four references
-constexpr uint32_t kMaxStack = 64;         // traversal stack entries: LDS short stack (24) + private spill (40)
+constexpr uint32_t kMaxStack = 64;         // traversal stack entries: LDS short stack (20) + private spill (44)
 
 struct ShadeLaunch {
     GConstDev g;
