@@ -381,3 +381,36 @@ def test_cpp_host_renders_the_same_frame(small, tmp_path):
     olight, _ = osc.reference_mode(og, ogb, odepth)
     assert np.array_equal(data[0].view(np.uint32), olight.view(np.uint32))
     assert np.allclose(data[1], osc.postprocess(og, odepth, olight), atol=2e-5, rtol=1e-4)
+
+
+def test_native_asset_pipeline_renders_the_oracle_frame(tmp_path):
+    """Files in, pixels out, no Python in between: asset_tool (C++: glTF + PNG + EXR decoders -> C ABI -> pass graph) renders
+    a textured scene from a .glb, a ZIP-compressed .exr and the reference's bluenoise.png; the oracle, fed by the Python
+    loaders from the same files, must agree bit for bit."""
+    import subprocess
+    from pathlib import Path
+
+    host = Path(__file__).resolve().parent.parent / "raytracer3_amd" / "host"
+    subprocess.check_call(["make", "-C", str(host), "asset_tool"], stdout=subprocess.DEVNULL)
+    mesh = scenes.textured_cornell()
+    glb, exr = tmp_path / "scene.glb", tmp_path / "sky.exr"
+    assets.write_glb(glb, mesh)
+    assets.write_exr(exr, scenes.sky(128, 64), "zip")
+    bn_png = Path(__file__).resolve().parent.parent / "resources" / "bluenoise.png"
+    W, H, spp, bounces = 80, 60, 4, 3
+    c = scenes.CORNELL_CAMERA
+    out = tmp_path / "out.bin"
+    args = [str(host / "asset_tool"), "render", str(glb), str(exr), str(bn_png), W, H, spp, bounces, SPEC, *c["position"], *c["direction"], 65.0, str(out)]
+    subprocess.check_call([str(a) for a in args])
+    data = np.fromfile(out, "<f4").reshape(2, H, W, 4)
+    ref_mesh, ref_sky, bn = assets.GltfMeshLoader.load(glb), assets.read_exr(exr), assets.load_bluenoise()
+    osc = orc.Scene(ref_mesh, ref_sky, bn)
+    cam = Camera(c["position"], c["direction"], math.radians(65.0), W / H)
+    g = cam.gconst((W, H))
+    g.samples, g.bounces, g.frame, g.blendfactor = spp, bounces, 0, 1.0
+    g.pad[0] = SPEC
+    og = as_orc(g)
+    ogb, odepth = osc.gbuffer(og)
+    olight, _ = osc.reference_mode(og, ogb, odepth)
+    assert (odepth != L.BACKGROUND_DEPTH).mean() > 0.5 and olight[..., :3].mean() > 0
+    assert np.array_equal(data[0].view(np.uint32), olight.view(np.uint32))

@@ -1,0 +1,234 @@
+"""The native (C++) asset pipeline of raytracer3_amd/host/assets.hpp against the Python loaders of raytracer3_amd/assets.py:
+glTF binary (transforms, strides, index widths, missing normals, emissive strength, embedded PNG textures), PNG colour
+types, scanline EXR (none / ZIPS / ZIP, FLOAT / HALF) and the bincode processed-asset file the reference tree ships."""
+import json
+import struct
+import subprocess
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from raytracer3_amd import assets, scenes
+
+ROOT = Path(__file__).resolve().parent.parent
+HOST = ROOT / "raytracer3_amd" / "host"
+TOOL = HOST / "asset_tool"
+
+
+@pytest.fixture(scope="module")
+def tool():
+    subprocess.check_call(["make", "-C", str(HOST), "asset_tool"], stdout=subprocess.DEVNULL)
+    assert TOOL.exists()
+    return str(TOOL)
+
+
+def run(tool, *args):
+    r = subprocess.run([tool, *map(str, args)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return r.stdout
+
+
+def manifest(d):
+    return [ln.split() for ln in (Path(d) / "manifest.txt").read_text().splitlines()]
+
+
+def load_dump(d):
+    d = Path(d)
+    v = np.fromfile(d / "vertices.bin", np.float32).reshape(-1, 8)
+    i = np.fromfile(d / "indices.bin", np.uint32)
+    g = np.fromfile(d / "geometries.bin", assets.GEOMETRY_DTYPE)
+    c = np.fromfile(d / "prim_counts.bin", np.uint32)
+    tex = [np.fromfile(d / f"texture_{m[1]}.bin", np.uint8).reshape(int(m[3]), int(m[2]), 4) for m in manifest(d) if m[0] == "texture"]
+    names = [" ".join(m[1:]) for m in manifest(d) if m[0] == "name"]
+    return v, i, g, c, tex, names
+
+
+def test_glb_roundtrip_matches_python_loader(tool, tmp_path):
+    mesh = scenes.textured_cornell()
+    glb = tmp_path / "cornell.glb"
+    assets.write_glb(glb, mesh)
+    run(tool, "glb", glb, tmp_path)
+    v, i, g, c, tex, names = load_dump(tmp_path)
+    ref = assets.GltfMeshLoader.load(glb)
+    assert np.array_equal(v.view(np.uint32), ref.vertices.view(np.uint32)) and np.array_equal(i, ref.indices)
+    assert g.tobytes() == ref.geometries.tobytes() and np.array_equal(c, ref.prim_counts)
+    assert len(tex) == len(ref.textures) > 0 and all(np.array_equal(a, b) for a, b in zip(tex, ref.textures))
+    assert names == ref.names
+    # and the file round-trips the scene itself
+    assert np.array_equal(v.view(np.uint32), mesh.vertices.view(np.uint32)) and np.array_equal(i, mesh.indices)
+
+
+def handmade_glb(path):
+    """Two nodes (one rotated / scaled / translated with a child using a matrix), u16 + u8 indices, an interleaved
+    vertex buffer (byteStride), a primitive without normals, a non-triangle primitive (skipped), emissive strength."""
+    rng = np.random.default_rng(5)
+    blob = bytearray()
+    views, accessors = [], []
+
+    def view(b, stride=None):
+        while len(blob) % 4:
+            blob.append(0)
+        v = {"buffer": 0, "byteOffset": len(blob), "byteLength": len(b)}
+        if stride:
+            v["byteStride"] = stride
+        blob.extend(b)
+        views.append(v)
+        return len(views) - 1
+
+    # interleaved p,n,uv (stride 32) for a 4x4 grid
+    n = 16
+    gx, gy = np.meshgrid(np.arange(4), np.arange(4))
+    pos = np.stack([gx.ravel(), rng.uniform(0, 0.3, n), gy.ravel()], 1).astype("<f4")
+    nrm = rng.normal(size=(n, 3))
+    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype("<f4")
+    uv = rng.uniform(0, 1, (n, 2)).astype("<f4")
+    inter = np.concatenate([pos, nrm, uv], 1).astype("<f4").tobytes()
+    bv = view(inter, 32)
+    for off, typ in ((0, "VEC3"), (12, "VEC3"), (24, "VEC2")):
+        accessors.append({"bufferView": bv, "byteOffset": off, "componentType": 5126, "count": n, "type": typ})
+    tris = np.array([[y * 4 + x, y * 4 + x + 1, (y + 1) * 4 + x] for y in range(3) for x in range(3)], "<u2")
+    accessors.append({"bufferView": view(tris.tobytes()), "componentType": 5123, "count": tris.size, "type": "SCALAR"})
+    tris8 = np.array([[(y + 1) * 4 + x, y * 4 + x + 1, (y + 1) * 4 + x + 1] for y in range(3) for x in range(3)], "u1")
+    accessors.append({"bufferView": view(tris8.tobytes()), "componentType": 5121, "count": tris8.size, "type": "SCALAR"})
+    pos2 = rng.uniform(-1, 1, (9, 3)).astype("<f4")
+    accessors.append({"bufferView": view(pos2.tobytes()), "componentType": 5126, "count": 9, "type": "VEC3"})
+    doc = {
+        "asset": {"version": "2.0"},
+        "scene": 0,
+        "scenes": [{"nodes": [0, 2]}],
+        "nodes": [
+            {"mesh": 0, "translation": [1.5, -2.0, 0.25], "rotation": [0.1825742, 0.3651484, 0.5477226, 0.7302967], "scale": [1.0, 2.0, 0.5], "children": [1]},
+            {"mesh": 1, "matrix": [0.0, 0.0, -1.0, 0.0, 0.0, 1.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 3.0, 0.5, -1.0, 1.0]},
+            {"mesh": 0},
+        ],
+        "meshes": [
+            {"name": "grid", "primitives": [
+                {"attributes": {"POSITION": 0, "NORMAL": 1, "TEXCOORD_0": 2}, "indices": 3, "material": 0},
+                {"attributes": {"POSITION": 0, "NORMAL": 1}, "indices": 4, "material": 1},
+                {"attributes": {"POSITION": 0}, "indices": 3, "mode": 1},
+            ]},
+            {"primitives": [{"attributes": {"POSITION": 5}}]},
+        ],
+        "materials": [
+            {"pbrMetallicRoughness": {"baseColorFactor": [0.1, 0.7, 0.3, 1.0], "metallicFactor": 0.25, "roughnessFactor": 0.6},
+             "emissiveFactor": [1.0, 0.5, 0.25], "extensions": {"KHR_materials_emissive_strength": {"emissiveStrength": 3.5}}},
+            {"pbrMetallicRoughness": {}},
+        ],
+        "accessors": accessors, "bufferViews": views, "buffers": [{"byteLength": len(blob)}],
+    }
+    js = json.dumps(doc, indent=1).encode()  # pretty-printed: exercises the parser's whitespace handling
+    js += b" " * ((-len(js)) % 4)
+    while len(blob) % 4:
+        blob.append(0)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<4sII", b"glTF", 2, 12 + 8 + len(js) + 8 + len(blob)))
+        f.write(struct.pack("<I4s", len(js), b"JSON") + js)
+        f.write(struct.pack("<I4s", len(blob), b"BIN\0") + bytes(blob))
+
+
+def test_glb_transforms_strides_and_missing_attributes(tool, tmp_path):
+    glb = tmp_path / "hand.glb"
+    handmade_glb(glb)
+    run(tool, "glb", glb, tmp_path)
+    v, i, g, c, tex, names = load_dump(tmp_path)
+    ref = assets.GltfMeshLoader.load(glb)
+    assert len(g) == 5 and names == ref.names == ["grid.0", "grid.1", "mesh.0", "grid.0", "grid.1"]
+    assert np.array_equal(i, ref.indices) and np.array_equal(c, ref.prim_counts) and g.tobytes() == ref.geometries.tobytes()
+    # transforms are applied in float64 on both sides; BLAS and the scalar loop may round the last bit differently
+    assert np.allclose(v, ref.vertices, rtol=0, atol=2e-6)
+    assert np.array_equal(v[-32:].view(np.uint32), ref.vertices[-32:].view(np.uint32))  # identity node: bit-exact pass-through
+    assert np.allclose(np.linalg.norm(v[:, 3:6], axis=1), 1.0, atol=1e-6)
+    assert np.allclose(g["emission"][0][:3], [3.5, 1.75, 0.875]) and g["base_color_texture_index"][0] == -1
+
+
+@pytest.mark.parametrize("mode", ["RGBA", "RGB", "L", "LA", "P", "1"])
+def test_png_decoder_matches_pillow(tool, tmp_path, mode):
+    from PIL import Image
+
+    rng = np.random.default_rng(3)
+    rgba = rng.integers(0, 256, (37, 53, 4), dtype=np.uint8)
+    im = Image.fromarray(rgba, "RGBA").convert(mode)
+    p = tmp_path / f"{mode}.png"
+    im.save(p, format="PNG")
+    run(tool, "png", p, tmp_path)
+    m = manifest(tmp_path)[0]
+    got = np.fromfile(tmp_path / "image.bin", np.uint8).reshape(int(m[2]), int(m[1]), 4)
+    assert np.array_equal(got, np.array(Image.open(p).convert("RGBA"), np.uint8))
+
+
+def test_png_decoder_on_the_reference_bluenoise(tool, tmp_path):
+    run(tool, "png", ROOT / "resources" / "bluenoise.png", tmp_path)
+    m = manifest(tmp_path)[0]
+    got = np.fromfile(tmp_path / "image.bin", np.uint8).reshape(int(m[2]), int(m[1]), 4)
+    assert np.array_equal(got, assets.load_bluenoise())
+
+
+@pytest.mark.parametrize("compression", ["none", "zips", "zip"])
+def test_exr_reader_matches_python(tool, tmp_path, compression):
+    sky = scenes.sky(96, 40).astype(np.float32)
+    sky[3, 5] = [5e4, 4e4, 3e4]
+    p = tmp_path / "sky.exr"
+    assets.write_exr(p, sky, compression)
+    run(tool, "exr", p, tmp_path)
+    m = manifest(tmp_path)[0]
+    got = np.fromfile(tmp_path / "sky.bin", np.float32).reshape(int(m[2]), int(m[1]), 3)
+    assert np.array_equal(got.view(np.uint32), sky.view(np.uint32))
+    assert np.array_equal(got.view(np.uint32), assets.read_exr(p).view(np.uint32))
+
+
+def test_exr_half_channels(tool, tmp_path):
+    """HALF pixels (what most tools write) incl. subnormals, infinities and an alpha channel that is ignored."""
+    w, h = 7, 3
+    vals = np.array([0.0, 1.0, -2.5, 6.1e-5, 5.96e-8, 65504.0, np.inf, 0.333251953125], np.float16)
+    rng = np.random.default_rng(9)
+    img = vals[rng.integers(0, len(vals), (h, w, 4))]
+
+    def attr(name, typ, payload):
+        return name.encode() + b"\0" + typ.encode() + b"\0" + struct.pack("<I", len(payload)) + payload
+
+    chl = b"".join(n.encode() + b"\0" + struct.pack("<iBBBBii", 1, 0, 0, 0, 0, 1, 1) for n in ("A", "B", "G", "R")) + b"\0"
+    box = struct.pack("<iiii", 0, 0, w - 1, h - 1)
+    head = struct.pack("<II", 20000630, 2) + attr("channels", "chlist", chl) + attr("compression", "compression", b"\0") + attr("dataWindow", "box2i", box) \
+        + attr("displayWindow", "box2i", box) + attr("lineOrder", "lineOrder", b"\0") + attr("pixelAspectRatio", "float", struct.pack("<f", 1.0)) \
+        + attr("screenWindowCenter", "v2f", struct.pack("<ff", 0.0, 0.0)) + attr("screenWindowWidth", "float", struct.pack("<f", 1.0)) + b"\0"
+    line = 8 + 2 * 4 * w
+    body = b"".join(struct.pack("<iI", y, 8 * w) + b"".join(img[y, :, c].astype("<f2").tobytes() for c in (3, 2, 1, 0)) for y in range(h))
+    p = tmp_path / "half.exr"
+    p.write_bytes(head + np.arange(h, dtype="<u8").__mul__(line).__add__(len(head) + 8 * h).tobytes() + body)
+    run(tool, "exr", p, tmp_path)
+    got = np.fromfile(tmp_path / "sky.bin", np.float32).reshape(h, w, 3)
+    want = img[:, :, :3].astype(np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(got.view(np.uint32), assets.read_exr(p).view(np.uint32))
+
+
+def test_bincode_processed_asset_of_the_reference_tree(tool, tmp_path):
+    src = ROOT / "tests" / "golden" / "processed_box.glb.bin"
+    run(tool, "bincode", src, "old", tmp_path)
+    ref = assets.read_processed_mesh(src, layout="old")
+    mf = {m[0]: int(m[1]) for m in manifest(tmp_path)}
+    assert mf == {"meshlets": len(ref.meshlets), "materials": len(ref.materials), "vertices": len(ref.vertices), "indices": len(ref.indices), "uploaded": int(ref.uploaded)}
+    v = np.fromfile(tmp_path / "vertices.bin", np.float32).reshape(-1, 8)
+    assert np.array_equal(v.view(np.uint32), ref.vertices.view(np.uint32))
+    mats = np.fromfile(tmp_path / "materials.bin", np.float32).reshape(-1, 6)
+    want = np.array([[*m.color, m.metalic_factor, m.roughness_factor, m.texture_offset] for m in ref.materials], np.float32)
+    assert np.array_equal(mats, want)
+    # current layout: round trip through the Python writer
+    cur = tmp_path / "cur.bin"
+    pm = assets.ProcessedMesh(np.array([[0, 0, 24, 12], [24, 36, 300, 70000]], np.uint32), ref.materials, ref.vertices, np.arange(200, dtype=np.uint8), True)
+    assets.write_processed_mesh(cur, pm)
+    run(tool, "bincode", cur, "current", tmp_path)
+    assert np.array_equal(np.fromfile(tmp_path / "meshlets.bin", np.uint32).reshape(-1, 4), pm.meshlets)
+    assert np.array_equal(np.fromfile(tmp_path / "indices.bin", np.uint8), pm.indices)
+
+
+def test_loader_errors_are_reported(tool, tmp_path):
+    bad = tmp_path / "bad.glb"
+    bad.write_bytes(b"glTF" + struct.pack("<II", 1, 12))
+    r = subprocess.run([tool, "glb", str(bad), str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 1 and "not a glTF 2 binary" in r.stderr
+    jpg = tmp_path / "x.png"
+    jpg.write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 32)
+    r = subprocess.run([tool, "png", str(jpg), str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 1 and "not a PNG" in r.stderr
