@@ -108,7 +108,7 @@ def main():
     def frame(i):
         g = pt.make_gconst(cam, args.spp, args.bounces, frame=i, flags=DEFAULT_FLAGS if args.flags < 0 else args.flags)
         pt.render(g, postprocess=False, wait=False)
-        return pt.gather_light(dist, torch) if world > 1 else None, g
+        return pt.gather_light(dist, torch, download=False) if world > 1 else None, g  # the frame is assembled in rank 0's HBM; no host copy in the timed region
 
     for i in range(args.warmup):
         frame(i)

@@ -117,11 +117,12 @@ class PathTracer:
     def tile_pixel_count(self, rank):
         return self.ctx.tile_pixel_count(rank, self.n_ranks)
 
-    def gather_light(self, dist=None, torch=None, dst=0):
+    def gather_light(self, dist=None, torch=None, dst=0, download=True):
         """Pack this rank's tiles of `Light`, gather them on `dst` with ONE collective and untile there.
-        Returns the full (H, W, 4) image on `dst` (None elsewhere).  With n_ranks == 1 no collective is issued."""
+        Returns the full (H, W, 4) image on `dst` (None elsewhere); with download=False the assembled frame stays in
+        `dst`'s HBM (the `Light` image) and True is returned instead.  With n_ranks == 1 no collective is issued."""
         if self.n_ranks == 1:
-            return self.light()
+            return self.light() if download else True
         counts = [self.tile_pixel_count(r) for r in range(self.n_ranks)]
         dev = torch.device("cuda", torch.cuda.current_device())
         lib, h, img = self.ctx.lib, self.ctx.h, self.handles["light"]
@@ -150,7 +151,7 @@ class PathTracer:
         if not done:
             return None
         self.ctx.wait()
-        return self.light()
+        return self.light() if download else True
 
 
 def gather_tiles(dist, torch, device, rank, n_ranks, counts, pack, unpack, dst=0):
