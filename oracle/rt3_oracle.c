@@ -403,7 +403,7 @@ struct orc_scene {
     orc_geometry_info *geoms; uint32_t *prim_counts, *first_prim; uint32_t n_geoms;
     uint32_t n_prims; uint32_t *prim_geom;
     /* accel */
-    uint32_t n_tris, n_nodes, max_depth, leaf_max, node_width, node_quant;
+    uint32_t n_tris, n_nodes, max_depth, leaf_max, node_width, node_quant, collapse;
     float *nodes;   /* 16 words per node */
     float *tris;    /* 12 words per tri (Morton order) */
     uint64_t *codes;
@@ -422,6 +422,7 @@ orc_scene *orc_scene_create(void) {
     s->leaf_max = 2;
     s->node_width = 4;
     s->node_quant = 1;
+    s->collapse = 1;
     for (int i = 0; i < 256; i++) { /* sRGB EOTF, IEC 61966-2-1, in double */
         double c = i / 255.0;
         s->srgb_lut[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
@@ -434,6 +435,7 @@ void orc_accel_set_layout(orc_scene *s, uint32_t leaf_max, uint32_t node_width, 
     s->node_width = node_width == 2 ? 2 : 4;
     s->node_quant = s->node_width == 4 ? (quantized > 2 ? 2 : quantized) : 0; /* 0 fp32 128 B, 1 quantised 64 B, 2 compact 48 B */
 }
+void orc_accel_set_collapse(orc_scene *s, uint32_t mode) { s->collapse = mode ? 1u : 0u; }
 uint32_t orc_accel_node_words(const orc_scene *s) { return s->node_width == 2 ? 16u : (s->node_quant == 2 ? 12u : (s->node_quant ? 16u : 32u)); }
 
 /* [north_star] 64-byte four-wide node with quantised child boxes:
@@ -670,6 +672,28 @@ static int delta_fn(const uint64_t *codes, int n, int i, int j) {
     if (a != b) return __builtin_clzll(a ^ b);
     return 64 + __builtin_clz((uint32_t)i ^ (uint32_t)j);
 }
+/* child slots of four-wide node i under the surface-area collapse (see orc_accel_build); half area = (ex*ey + ey*ez) + ez*ex */
+static uint32_t sah_slots(uint32_t i, const uint32_t *left, const uint32_t *right, const uint32_t *rcnt, const float *nmin, const float *nmax,
+                          uint32_t K, uint32_t sl[4]) {
+    uint32_t ns = 2;
+    sl[0] = left[i]; sl[1] = right[i];
+    for (int it = 0; it < 2; it++) {
+        int best = -1; float ba = -1.0f;
+        for (uint32_t k = 0; k < ns; k++) {
+            uint32_t ch = sl[k];
+            if ((ch & 0x80000000u) || rcnt[ch] <= K) continue;
+            float ex = nmax[3 * ch] - nmin[3 * ch], ey = nmax[3 * ch + 1] - nmin[3 * ch + 1], ez = nmax[3 * ch + 2] - nmin[3 * ch + 2];
+            float a = (ex * ey + ey * ez) + ez * ex;
+            if (a > ba) { ba = a; best = (int)k; }
+        }
+        if (best < 0) break;
+        uint32_t ch = sl[best];
+        for (int k = (int)ns; k > best + 1; k--) sl[k] = sl[k - 1];
+        sl[best] = left[ch]; sl[best + 1] = right[ch];
+        ns++;
+    }
+    return ns;
+}
 int orc_accel_build(orc_scene *s) {
     accel_free(s);
     uint32_t n = s->n_prims;
@@ -793,7 +817,29 @@ int orc_accel_build(orc_scene *s) {
          * Surviving nodes are renumbered densely in index order (an exclusive scan on the GPU). */
         const uint32_t K = s->leaf_max, W4 = s->node_width == 4;
 #define ORC_LIVE(i) ((i) == 0 || rcnt[i] > K)
-#define ORC_KEEP(i) (ORC_LIVE(i) && (!W4 || (depth[i] & 1u) == 0))
+        /* which binary nodes survive as four-wide nodes.  collapse 0: the nodes at even binary depth (each absorbs its live
+         * children).  collapse 1 (default): top-down from the root, a node's two child slots are grown to (up to) four by
+         * repeatedly replacing the live internal slot of LARGEST SURFACE AREA by its two children (ties: first slot); the
+         * live internal slots that remain are the next surviving nodes.  wlevel = four-wide level of a surviving node. */
+        uint8_t *keepf = (uint8_t *)calloc(nn, 1);
+        uint32_t *wlevel = (uint32_t *)calloc(nn, 4);
+        if (W4 && s->collapse) {
+            uint32_t *queue = (uint32_t *)malloc((size_t)nn * 4), qh = 0, qt = 0;
+            queue[qt++] = 0; keepf[0] = 1;
+            while (qh < qt) {
+                uint32_t i = queue[qh++], sl[4], m = sah_slots(i, left, right, rcnt, nmin, nmax, K, sl);
+                for (uint32_t k = 0; k < m; k++)
+                    if (!(sl[k] & 0x80000000u) && rcnt[sl[k]] > K) { keepf[sl[k]] = 1; wlevel[sl[k]] = wlevel[i] + 1; queue[qt++] = sl[k]; }
+            }
+            free(queue);
+        } else {
+            for (uint32_t i = 0; i < nn; i++) { keepf[i] = ORC_LIVE(i) && (!W4 || (depth[i] & 1u) == 0); wlevel[i] = W4 ? depth[i] / 2u : depth[i]; }
+        }
+#define ORC_KEEP(i) (keepf[i])
+#define ORC_SLOTS(i, sl, m) do { if (W4 && s->collapse) m = sah_slots(i, left, right, rcnt, nmin, nmax, K, sl); else { \
+            uint32_t c2_[2] = {left[i], right[i]}; m = 0; \
+            for (int c_ = 0; c_ < 2; c_++) { uint32_t ch_ = c2_[c_]; \
+                if (W4 && !(ch_ & 0x80000000u) && ORC_LIVE(ch_)) { sl[m++] = left[ch_]; sl[m++] = right[ch_]; } else sl[m++] = ch_; } } } while (0)
         uint32_t *newidx = (uint32_t *)malloc((size_t)nn * 4), kept = 0, maxd = 0;
         for (uint32_t i = 0; i < nn; i++) { newidx[i] = kept; if (ORC_KEEP(i)) kept++; }
         const uint32_t QN = s->node_quant;
@@ -810,37 +856,27 @@ int orc_accel_build(orc_scene *s) {
             for (uint32_t i = 0; i < nn; i++) {
                 cbase[i] = ci; tbase[i] = ti;
                 if (!ORC_KEEP(i)) continue;
-                uint32_t c2[2] = {left[i], right[i]};
-                for (int c = 0; c < 2; c++) {
-                    uint32_t ch = c2[c], sl[2], m = 0;
-                    if (!(ch & 0x80000000u) && ORC_LIVE(ch)) { sl[m++] = left[ch]; sl[m++] = right[ch]; } else sl[m++] = ch;
-                    for (uint32_t k = 0; k < m; k++) {
-                        if (sl[k] & 0x80000000u) ti += 1;
-                        else if (ORC_LIVE(sl[k])) ci += 1;
-                        else ti += rcnt[sl[k]];
-                    }
+                uint32_t sl[4], m;
+                ORC_SLOTS(i, sl, m);
+                for (uint32_t k = 0; k < m; k++) {
+                    if (sl[k] & 0x80000000u) ti += 1;
+                    else if (ORC_LIVE(sl[k])) ci += 1;
+                    else ti += rcnt[sl[k]];
                 }
             }
             newidx[0] = 0;
             for (uint32_t i = 0; i < nn; i++) {
                 if (!ORC_KEEP(i)) continue;
-                uint32_t c2[2] = {left[i], right[i]}, rank = 0;
-                for (int c = 0; c < 2; c++) {
-                    uint32_t ch = c2[c], sl[2], m = 0;
-                    if (!(ch & 0x80000000u) && ORC_LIVE(ch)) { sl[m++] = left[ch]; sl[m++] = right[ch]; } else sl[m++] = ch;
-                    for (uint32_t k = 0; k < m; k++)
-                        if (!(sl[k] & 0x80000000u) && ORC_LIVE(sl[k])) newidx[sl[k]] = 1u + cbase[i] + rank++;
-                }
+                uint32_t sl[4], m, rank = 0;
+                ORC_SLOTS(i, sl, m);
+                for (uint32_t k = 0; k < m; k++)
+                    if (!(sl[k] & 0x80000000u) && ORC_LIVE(sl[k])) newidx[sl[k]] = 1u + cbase[i] + rank++;
             }
         }
         for (uint32_t i = 0; i < nn; i++) {
             if (!ORC_KEEP(i)) continue;
-            uint32_t slots[4], ns = 0, c2[2] = {left[i], right[i]};
-            for (int c = 0; c < 2; c++) {
-                uint32_t ch = c2[c];
-                if (W4 && !(ch & 0x80000000u) && ORC_LIVE(ch)) { slots[ns++] = left[ch]; slots[ns++] = right[ch]; } /* absorbed */
-                else slots[ns++] = ch;
-            }
+            uint32_t slots[4], ns;
+            ORC_SLOTS(i, slots, ns);
             float *nd = s->nodes + (size_t)words * newidx[i];
             float qmn[4][3], qmx[4][3]; uint32_t qref[4], qmeta[4] = {7u, 7u, 7u, 7u}, tcur = QN == 2 ? tbase[i] : 0u;
             for (uint32_t k = 0; k < (W4 ? 4u : 2u); k++) {
@@ -868,8 +904,7 @@ int orc_accel_build(orc_scene *s) {
             }
             if (QN == 2) compact_node(qmn, qmx, qmeta, ns, 1u + cbase[i], tbase[i], (uint32_t *)nd);
             else if (QN) quantize_node(qmn, qmx, qref, ns, (uint32_t *)nd);
-            uint32_t lvl = (W4 ? depth[i] / 2u : depth[i]) + 2u; /* levels from the root to this node's leaf slots */
-            if (!W4) { /* binary: collapsed ancestors do not exist, every live ancestor is a level */ }
+            uint32_t lvl = wlevel[i] + 2u; /* levels from the root to this node's leaf slots */
             if (lvl > maxd) maxd = lvl;
         }
         s->max_depth = maxd;
@@ -877,6 +912,8 @@ int orc_accel_build(orc_scene *s) {
         if (QN == 2) { free(s->tris); s->tris = tris2; free(cbase); free(tbase); }
 #undef ORC_LIVE
 #undef ORC_KEEP
+#undef ORC_SLOTS
+        free(keepf); free(wlevel);
         free(left); free(right); free(rlo); free(rcnt); free(nmin); free(nmax); free(stack); free(state); free(depth); free(newidx);
     }
     free(bmin); free(bmax); free(cp); free(lmin); free(lmax);

@@ -107,6 +107,8 @@ int orc_scene_set_texture(orc_scene *s, uint32_t index, const uint8_t *rgba_srgb
  * quantized (width 4 only): 0 = 128 B fp32 boxes, 1 = 64 B nodes with 8-bit conservative child boxes and explicit
  * references, 2 = compact 48 B nodes (same boxes; references implied by node_base / tri_base + one nibble per child) */
 void orc_accel_set_layout(orc_scene *s, uint32_t leaf_max, uint32_t node_width, uint32_t quantized);
+/* four-wide collapse rule: 1 = surface-area greedy (default), 0 = even binary depth */
+void orc_accel_set_collapse(orc_scene *s, uint32_t mode);
 uint32_t orc_accel_node_words(const orc_scene *s);
 int orc_accel_build(orc_scene *s);
 uint32_t orc_accel_num_tris(const orc_scene *s);

@@ -94,7 +94,7 @@ struct rt3_ctx {
     int64_t opt_batch_spp = 0;
     bool opt_profile = false, opt_count = false;
     int opt_variant = 0;  // RT3_OPT_EXTEND_VARIANT: reserved for traversal experiments
-    uint32_t opt_leaf_size = 2, opt_node_width = 4, opt_node_quant = 1;
+    uint32_t opt_leaf_size = 2, opt_node_width = 4, opt_node_quant = 1, opt_collapse = 1;
     rt3_stats stats;
     uint64_t primary_rays_pending = 0;
     std::vector<Timed> pending_events;
@@ -562,6 +562,11 @@ int rt3_set_option(rt3_ctx* c, int option, int64_t value) {
             c->opt_node_quant = (uint32_t)value;
             c->accel_built = false;
             return RT3_OK;
+        case RT3_OPT_WIDE_COLLAPSE:
+            if (value != 0 && value != 1) return fail(c, RT3_E_INVALID, "wide collapse must be 0 (even depth) or 1 (surface area)");
+            c->opt_collapse = (uint32_t)value;
+            c->accel_built = false;
+            return RT3_OK;
         case RT3_OPT_NODE_WIDTH:
             if (value != 2 && value != 4) return fail(c, RT3_E_INVALID, "node width must be 2 or 4");
             c->opt_node_width = (uint32_t)value;
@@ -767,7 +772,7 @@ int rt3_accel_build(rt3_ctx* c, uint32_t* out_handle) {
     dev_free(c->bvh.tris);
     dev_free(c->bvh.tri_shade);
     hipError_t e = lbvh_build(c->stream, c->d_verts, c->d_indices, c->d_geoms, c->d_prim_geom, c->d_first_prim, c->n_prims, c->opt_leaf_size,
-                              c->opt_node_width, c->opt_node_quant, &c->bvh);
+                              c->opt_node_width, c->opt_node_quant, c->opt_collapse, &c->bvh);
     if (e != hipSuccess) return fail(c, RT3_E_HIP, std::string("lbvh_build: ") + hipGetErrorString(e));
     // worst-case stack use of the near-first walk: (children per node - 1) entries per level above the leaves
     const uint32_t stack_need = c->bvh.max_depth > 1 ? (c->opt_node_width - 1) * (c->bvh.max_depth - 1) : 0;

@@ -85,6 +85,7 @@ struct LbvhResult {
     uint32_t n_nodes = 0, n_tris = 0, max_depth = 0;
 };
 hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,
-                      const uint32_t* first_prim, uint32_t n_prims, uint32_t leaf_max, uint32_t node_width, uint32_t node_quant, LbvhResult* out);
+                      const uint32_t* first_prim, uint32_t n_prims, uint32_t leaf_max, uint32_t node_width, uint32_t node_quant, uint32_t collapse_mode,
+                      LbvhResult* out);
 
 }  // namespace rt3

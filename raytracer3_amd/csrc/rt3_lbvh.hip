@@ -357,11 +357,41 @@ __device__ void compact_node(const float (*mn)[3], const float (*mx)[3], const u
         out[k] = make_float4(__uint_as_float(w[4 * k]), __uint_as_float(w[4 * k + 1]), __uint_as_float(w[4 * k + 2]), __uint_as_float(w[4 * k + 3]));
 }
 
-// child slots of surviving node i, in tree order: with four-wide nodes a child that is itself a live internal node is
-// absorbed (its two children take its place)
+// child slots of surviving node i, in tree order.  Four-wide nodes, collapse 0 (even binary depth): a child that is itself
+// a live internal node is absorbed (its two children take its place).  Collapse 1 (surface area, default): the two child
+// slots are grown to (up to) four by repeatedly replacing the live internal slot of largest surface area by its two
+// children (ties: first slot); half area = (ex*ey + ey*ez) + ez*ex in fp32, like the oracle.
 __device__ __forceinline__ uint32_t gather_slots(uint32_t i, const uint32_t* left, const uint32_t* right, const uint32_t* range_cnt,
-                                                 uint32_t leaf_max, int wide, uint32_t sl[4]) {
+                                                 const float* nbox, uint32_t leaf_max, int wide, int collapse, uint32_t sl[4]) {
     uint32_t ns = 0;
+    if (wide && collapse) {
+        ns = 2;
+        sl[0] = left[i];
+        sl[1] = right[i];
+        sl[2] = sl[3] = 0xFFFFFFFFu;
+        for (int it = 0; it < 2; it++) {
+            int best = -1;
+            float ba = -1.0f;
+            for (uint32_t k = 0; k < ns; k++) {
+                const uint32_t ch = sl[k];
+                if ((ch & 0x80000000u) || range_cnt[ch] <= leaf_max) continue;
+                const float ex = nbox[6 * (size_t)ch + 3] - nbox[6 * (size_t)ch], ey = nbox[6 * (size_t)ch + 4] - nbox[6 * (size_t)ch + 1],
+                            ez = nbox[6 * (size_t)ch + 5] - nbox[6 * (size_t)ch + 2];
+                const float a = (ex * ey + ey * ez) + ez * ex;
+                if (a > ba) {
+                    ba = a;
+                    best = (int)k;
+                }
+            }
+            if (best < 0) break;
+            const uint32_t ch = sl[best];
+            for (int k = (int)ns; k > best + 1; k--) sl[k] = sl[k - 1];
+            sl[best] = left[ch];
+            sl[best + 1] = right[ch];
+            ns++;
+        }
+        return ns;
+    }
     const uint32_t c2[2] = {left[i], right[i]};
 #pragma unroll
     for (int c = 0; c < 2; c++) {
@@ -377,14 +407,28 @@ __device__ __forceinline__ uint32_t gather_slots(uint32_t i, const uint32_t* lef
     return ns;
 }
 
+// surface-area collapse, one four-wide level per launch: every node of the frontier survives; its live internal slots
+// form the next frontier
+__global__ void k_wide_level(const uint32_t* left, const uint32_t* right, const uint32_t* range_cnt, const float* nbox, uint32_t leaf_max,
+                             const uint32_t* frontier, uint32_t n_frontier, uint32_t* keep, uint32_t* next, uint32_t* n_next) {
+    for (uint32_t f = blockIdx.x * blockDim.x + threadIdx.x; f < n_frontier; f += gridDim.x * blockDim.x) {
+        const uint32_t i = frontier[f];
+        keep[i] = 1u;
+        uint32_t sl[4];
+        const uint32_t ns = gather_slots(i, left, right, range_cnt, nbox, leaf_max, 1, 1, sl);
+        for (uint32_t k = 0; k < ns; k++)
+            if (!(sl[k] & 0x80000000u) && range_cnt[sl[k]] > leaf_max) next[atomicAdd(n_next, 1u)] = sl[k];
+    }
+}
+
 // compact layout, pass 1: per surviving node the number of internal child slots and of triangles in leaf slots
-__global__ void k_child_counts(const uint32_t* left, const uint32_t* right, const uint32_t* range_cnt, const uint32_t* keep, uint32_t nn,
-                               uint32_t leaf_max, uint32_t* n_internal, uint32_t* n_leaf_tris) {
+__global__ void k_child_counts(const uint32_t* left, const uint32_t* right, const uint32_t* range_cnt, const float* nbox, const uint32_t* keep, uint32_t nn,
+                               uint32_t leaf_max, int collapse, uint32_t* n_internal, uint32_t* n_leaf_tris) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += gridDim.x * blockDim.x) {
         uint32_t ci = 0, ti = 0;
         if (keep[i]) {
             uint32_t sl[4];
-            const uint32_t ns = gather_slots(i, left, right, range_cnt, leaf_max, 1, sl);
+            const uint32_t ns = gather_slots(i, left, right, range_cnt, nbox, leaf_max, 1, collapse, sl);
             for (uint32_t k = 0; k < ns; k++) {
                 if (sl[k] & 0x80000000u) ti += 1u;
                 else if (range_cnt[sl[k]] > leaf_max) ci += 1u;
@@ -396,13 +440,13 @@ __global__ void k_child_counts(const uint32_t* left, const uint32_t* right, cons
     }
 }
 // compact layout, pass 2 (after the exclusive sums): a child's index is 1 + node_base(parent) + rank among the internal slots
-__global__ void k_assign_index(const uint32_t* left, const uint32_t* right, const uint32_t* range_cnt, const uint32_t* keep, uint32_t nn,
-                               uint32_t leaf_max, const uint32_t* cbase, uint32_t* newidx) {
+__global__ void k_assign_index(const uint32_t* left, const uint32_t* right, const uint32_t* range_cnt, const float* nbox, const uint32_t* keep, uint32_t nn,
+                               uint32_t leaf_max, int collapse, const uint32_t* cbase, uint32_t* newidx) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += gridDim.x * blockDim.x) {
         if (i == 0) newidx[0] = 0u;
         if (!keep[i]) continue;
         uint32_t sl[4], rank = 0;
-        const uint32_t ns = gather_slots(i, left, right, range_cnt, leaf_max, 1, sl);
+        const uint32_t ns = gather_slots(i, left, right, range_cnt, nbox, leaf_max, 1, collapse, sl);
         for (uint32_t k = 0; k < ns; k++)
             if (!(sl[k] & 0x80000000u) && range_cnt[sl[k]] > leaf_max) newidx[sl[k]] = 1u + cbase[i] + rank++;
     }
@@ -411,26 +455,14 @@ __global__ void k_assign_index(const uint32_t* left, const uint32_t* right, cons
 // one thread per surviving node: gather its 2 (binary) or 2..4 (wide: internal children are absorbed) child slots
 __global__ void k_emit_nodes(const uint32_t* left, const uint32_t* right, const uint32_t* range_lo, const uint32_t* range_cnt,
                              const uint32_t* keep, const uint32_t* newidx, const float* lmin, const float* lmax, const float* nbox,
-                             uint32_t nn, uint32_t leaf_max, int wide, int quant, float4* nodes, const uint32_t* cbase, const uint32_t* tbase,
+                             uint32_t nn, uint32_t leaf_max, int wide, int quant, int collapse, float4* nodes, const uint32_t* cbase, const uint32_t* tbase,
                              const float4* tris_morton, float4* tris_out) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += gridDim.x * blockDim.x) {
         if (!keep[i]) continue;
-        uint32_t s0 = left[i], s1 = right[i], s2 = 0xFFFFFFFFu, s3 = 0xFFFFFFFFu;
-        bool v2 = false, v3 = false;
-        if (wide) {  // absorb internal children that are not collapsed into leaves: their two children become slots
-            bool e0 = !(s0 & 0x80000000u) && range_cnt[s0] > leaf_max, e1 = !(s1 & 0x80000000u) && range_cnt[s1] > leaf_max;
-            uint32_t a0 = s0, a1 = s1;
-            if (e0 && e1) {
-                s0 = left[a0]; s1 = right[a0]; s2 = left[a1]; s3 = right[a1];
-                v2 = v3 = true;
-            } else if (e0) {
-                s0 = left[a0]; s1 = right[a0]; s2 = a1;
-                v2 = true;
-            } else if (e1) {
-                s1 = left[a1]; s2 = right[a1];
-                v2 = true;
-            }
-        }
+        uint32_t sl4[4];
+        const uint32_t ns4 = gather_slots(i, left, right, range_cnt, nbox, leaf_max, wide, collapse, sl4);
+        const uint32_t s0 = sl4[0], s1 = sl4[1], s2 = sl4[2], s3 = sl4[3];
+        const bool v2 = ns4 > 2, v3 = ns4 > 3;
         const uint32_t o = newidx[i];
         float mn[3], mx[3];
         uint32_t ref;
@@ -523,11 +555,12 @@ __global__ void k_single(const float* lmin, const float* lmax, int wide, int qua
     } while (0)
 
 hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,
-                      const uint32_t* first_prim, uint32_t n, uint32_t leaf_max, uint32_t node_width, uint32_t node_quant, LbvhResult* out) {
+                      const uint32_t* first_prim, uint32_t n, uint32_t leaf_max, uint32_t node_width, uint32_t node_quant, uint32_t collapse_mode,
+                      LbvhResult* out) {
     hipError_t err = hipSuccess;
     *out = LbvhResult{};
     out->n_tris = n;
-    const int wide = node_width == 4, quant = wide ? (node_quant > 2 ? 2 : (int)node_quant) : 0;
+    const int wide = node_width == 4, quant = wide ? (node_quant > 2 ? 2 : (int)node_quant) : 0, collapse = wide && collapse_mode ? 1 : 0;
     out->node_bytes = (wide && !quant) ? 128u : (quant == 2 ? 16u * kC48Stride : 64u);
     out->layout = !wide ? kLayoutBinary64 : (quant == 2 ? kLayoutWide48Q : (quant ? kLayoutWide64Q : kLayoutWide128));
     if (n == 0) return hipSuccess;
@@ -600,7 +633,35 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
     } else {
         hipLaunchKernelGGL(k_hierarchy, dim3(grid), dim3(256), 0, st, keys_out, (int)n, left, right, pint, pleaf, rlo, rcnt);
         hipLaunchKernelGGL(k_refit, dim3(grid), dim3(256), 0, st, left, right, pint, pleaf, lmin, lmax, n, nbox, arrive);
-        hipLaunchKernelGGL(k_keep_flags, dim3(grid), dim3(256), 0, st, pint, rcnt, nn, leaf_max, wide, keep, levels);
+        if (collapse) {
+            // top-down, one four-wide level per launch (the frontier of level l+1 is produced by level l); ~log4(n) launches
+            uint32_t *fr_a = nullptr, *fr_b = nullptr, *fr_n = nullptr, n_front = 1, wide_levels = 0;
+            const uint32_t root = 0;
+            hipError_t e2 = hipMalloc(&fr_a, (size_t)nn * 4);
+            if (e2 == hipSuccess) e2 = hipMalloc(&fr_b, (size_t)nn * 4);
+            if (e2 == hipSuccess) e2 = hipMalloc(&fr_n, 4);
+            if (e2 == hipSuccess) e2 = hipMemsetAsync(keep, 0, (size_t)nn * 4, st);
+            if (e2 == hipSuccess) e2 = hipMemcpyAsync(fr_a, &root, 4, hipMemcpyHostToDevice, st);
+            while (e2 == hipSuccess && n_front > 0) {
+                e2 = hipMemsetAsync(fr_n, 0, 4, st);
+                if (e2 != hipSuccess) break;
+                const unsigned g2 = (unsigned)((n_front + 255) / 256 > 4096 ? 4096 : (n_front + 255) / 256);
+                hipLaunchKernelGGL(k_wide_level, dim3(g2), dim3(256), 0, st, left, right, rcnt, nbox, leaf_max, fr_a, n_front, keep, fr_b, fr_n);
+                e2 = hipMemcpyAsync(&n_front, fr_n, 4, hipMemcpyDeviceToHost, st);
+                if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
+                std::swap(fr_a, fr_b);
+                ++wide_levels;
+            }
+            (void)hipFree(fr_a);
+            (void)hipFree(fr_b);
+            (void)hipFree(fr_n);
+            LB_CHECK(e2);
+            const uint32_t lv = wide_levels + 1;  // levels from the root down to the deepest node's leaf slots
+            LB_CHECK(hipMemcpyAsync(levels, &lv, 4, hipMemcpyHostToDevice, st));
+            LB_CHECK(hipStreamSynchronize(st));
+        } else {
+            hipLaunchKernelGGL(k_keep_flags, dim3(grid), dim3(256), 0, st, pint, rcnt, nn, leaf_max, wide, keep, levels);
+        }
         LB_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, temp2_bytes, keep, newidx, (int)nn, st));
         LB_CHECK(hipMalloc(&temp2, temp2_bytes ? temp2_bytes : 16));
         LB_CHECK(hipcub::DeviceScan::ExclusiveSum(temp2, temp2_bytes, keep, newidx, (int)nn, st));
@@ -611,13 +672,13 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
         out->n_nodes = tail[0] + tail[1];
         LB_CHECK(hipMalloc(&out->nodes, (size_t)out->n_nodes * out->node_bytes));
         if (quant == 2) {
-            hipLaunchKernelGGL(k_child_counts, dim3(grid), dim3(256), 0, st, left, right, rcnt, keep, nn, leaf_max, n_int, n_ltri);
+            hipLaunchKernelGGL(k_child_counts, dim3(grid), dim3(256), 0, st, left, right, rcnt, nbox, keep, nn, leaf_max, collapse, n_int, n_ltri);
             LB_CHECK(hipcub::DeviceScan::ExclusiveSum(temp2, temp2_bytes, n_int, cbase, (int)nn, st));
             LB_CHECK(hipcub::DeviceScan::ExclusiveSum(temp2, temp2_bytes, n_ltri, tbase, (int)nn, st));
-            hipLaunchKernelGGL(k_assign_index, dim3(grid), dim3(256), 0, st, left, right, rcnt, keep, nn, leaf_max, cbase, newidx);
+            hipLaunchKernelGGL(k_assign_index, dim3(grid), dim3(256), 0, st, left, right, rcnt, nbox, keep, nn, leaf_max, collapse, cbase, newidx);
         }
         hipLaunchKernelGGL(k_emit_nodes, dim3(grid), dim3(256), 0, st, left, right, rlo, rcnt, keep, newidx, lmin, lmax, nbox, nn, leaf_max, wide,
-                           quant, out->nodes, cbase, tbase, tris_morton, out->tris);
+                           quant, collapse, out->nodes, cbase, tbase, tris_morton, out->tris);
         LB_CHECK(hipGetLastError());
         LB_CHECK(hipStreamSynchronize(st));
     }

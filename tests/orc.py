@@ -45,6 +45,7 @@ def lib():
         for n in ("orc_scene_destroy", "orc_accel_build"):
             getattr(L, n).argtypes = [vp]
         L.orc_accel_set_layout.argtypes = [vp, u32, u32, u32]
+        L.orc_accel_set_collapse.argtypes = [vp, u32]
         L.orc_accel_node_words.restype = u32; L.orc_accel_node_words.argtypes = [vp]
         L.orc_scene_set_vertices.argtypes = [vp, vp, u32]
         L.orc_scene_set_indices.argtypes = [vp, vp, u32]
@@ -84,10 +85,11 @@ def camera_gconst(position, direction, fov_deg, width, height, z_near=0.1, z_far
 
 
 class Scene:
-    def __init__(self, mesh, sky=None, bluenoise=None, build=True, leaf_size=2, node_width=4, quantized=1):
+    def __init__(self, mesh, sky=None, bluenoise=None, build=True, leaf_size=2, node_width=4, quantized=1, collapse=1):
         L = lib()
         self.h = L.orc_scene_create()
         L.orc_accel_set_layout(self.h, leaf_size, node_width, quantized)
+        L.orc_accel_set_collapse(self.h, collapse)
         self.mesh = mesh
         v = np.ascontiguousarray(mesh.vertices, np.float32); i = np.ascontiguousarray(mesh.indices, np.uint32)
         L.orc_scene_set_vertices(self.h, ptr(v), len(v))

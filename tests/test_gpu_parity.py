@@ -82,6 +82,24 @@ def test_lbvh_bit_identical_to_oracle(small, leaf, width, quant):
     ctx.close()
 
 
+def test_lbvh_even_depth_collapse_still_available(small):
+    """RT3_OPT_WIDE_COLLAPSE = 0 (four-wide nodes from even binary depths, the first design) stays bit-identical too."""
+    mesh, sky, bn, _ = small
+    osc = orc.Scene(mesh, collapse=0)
+    ctx = Context(0)
+    ctx.set_option(L.OPT_WIDE_COLLAPSE, 0)
+    ctx.upload_mesh(mesh)
+    ctx.build_accel()
+    nodes, tris = ctx.accel_download()
+    assert ctx.accel_info()[:3] == (osc.n_nodes, osc.n_tris, osc.max_depth)
+    assert np.array_equal(nodes, osc.nodes()) and np.array_equal(tris, osc.tris())
+    rays = rays_random(5000, 6, [-14, 0.2, -8], [14, 12, 8])
+    t, u, v, p, cn, ct, _ = ctx.trace_rays(rays, counts=True)
+    ot, ou, ov, op, ocn, oct = osc.trace_closest(rays, counts=True)
+    assert np.array_equal(p, op) and np.array_equal(cn, ocn) and np.array_equal(ct, oct)
+    ctx.close()
+
+
 def test_lbvh_edge_cases():
     """empty scene, one triangle, duplicate triangles (identical Morton codes)."""
     ctx = Context(0)

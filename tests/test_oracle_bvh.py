@@ -40,6 +40,11 @@ def test_bvh_equals_bruteforce_fp32_and_tracks_fp64():
         at, au, av, ap = alt.trace_closest(rays)
         assert np.array_equal(ap, p) and np.array_equal(at, t) and np.array_equal(au, u) and np.array_equal(av, v)
         assert np.array_equal(alt.trace_any(rays) != 0, occ != 0)
+    # the surface-area collapse only regroups the same binary tree into better four-wide nodes: same hits, fewer visits
+    par = orc.Scene(mesh, collapse=0)
+    pt_, pu_, pv_, pp_, pnn, pnt = par.trace_closest(rays, counts=True)
+    assert np.array_equal(pp_, p) and np.array_equal(pt_, t) and nn.mean() < pnn.mean()
+    print("nodes/ray: parity collapse %.2f, surface-area collapse %.2f; nodes %d -> %d" % (pnn.mean(), nn.mean(), par.n_nodes, sc.n_nodes))
     assert 5 < nn.mean() < 200 and nt.mean() < 20
     hit = p != orc.MISS
     assert (u[hit] >= 0).all() and (v[hit] >= 0).all() and (u[hit] + v[hit] <= 1).all() and (t[hit] > 0.001).all()
