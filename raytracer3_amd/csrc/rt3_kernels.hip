@@ -454,8 +454,7 @@ __device__ __forceinline__ BlockAppend block_append2(bool want_ext, uint32_t* ex
     BlockAppend r;
     r.ext = lds[kWaves] + lds[wave] + (uint32_t)__popcll(m_ext & below);
     r.sh = lds[2 * kWaves + 1] + lds[kWaves + 1 + wave] + (uint32_t)__popcll(m_sh & below);
-    __syncthreads();  // lds is reused by the next loop iteration
-    return r;
+    return r;  // no third barrier: the caller alternates between two lds buffers from one loop iteration to the next
 }
 
 struct ShadeArgs {
@@ -492,7 +491,8 @@ struct ShadeArgs {
 // refrence_mode.slang:28-57 for one bounce of every live path
 template <bool FIRST>
 __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
-    __shared__ uint32_t append_lds[2 * (kShadeBlock / 64 + 1)];
+    __shared__ uint32_t append_lds[2][2 * (kShadeBlock / 64 + 1)];  // double-buffered: see block_append2
+    uint32_t parity = 0;
     const GConstDev& g = a.g;
     const uint32_t flags = g.pad[0], B = g.bounces, b = a.bounce;
     const uint32_t dims = flags ? 8u : 2u;
@@ -634,7 +634,8 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
                 emit_ext = b != B - 1;            // :53
             }
         }
-        const BlockAppend slot = block_append2(emit_ext, a.out_count, emit_shadow, a.sh_count, append_lds);
+        const BlockAppend slot = block_append2(emit_ext, a.out_count, emit_shadow, a.sh_count, append_lds[parity]);
+        parity ^= 1u;
         if (emit_shadow) {
             const uint32_t j = slot.sh;
             reinterpret_cast<float4*>(a.sh_rays)[j] = make_float4(o.x, o.y, o.z, kRayTMin);
