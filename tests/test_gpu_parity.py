@@ -432,3 +432,54 @@ def test_native_asset_pipeline_renders_the_oracle_frame(tmp_path):
     olight, _ = osc.reference_mode(og, ogb, odepth)
     assert (odepth != L.BACKGROUND_DEPTH).mean() > 0.5 and olight[..., :3].mean() > 0
     assert np.array_equal(data[0].view(np.uint32), olight.view(np.uint32))
+
+
+def test_full_size_frame_properties():
+    """BASELINE's C3 window (1920x1080, full atrium, 2048x1024 sky) through size-independent properties, where the oracle
+    would need minutes: (1) determinism -- out-of-order ray completion, atomics-based queue compaction and the dynamic ray
+    pool must not leak into the image; (2) the frame does not depend on the rank count (1 vs 4 ranks, tiles merged);
+    (3) linearity of the reference estimator: doubling every emission doubles the radiance exactly (power-of-two scaling
+    is exact in fp32); (4) sample batching (16 + 16 vs 4 x 8) leaves the bits alone; (5) closed-form bounds: finite,
+    non-negative, background pixels untouched; (6) a 64 x 64 window of the frame against the oracle, bit for bit."""
+    W, H, spp, B = 1920, 1080, 32, 4
+    mesh, sky, bn = scenes.atrium(1.0), scenes.sky(2048, 1024), assets.load_bluenoise()
+    cam = Camera(scenes.ATRIUM_CAMERA["position"], scenes.ATRIUM_CAMERA["direction"], math.radians(scenes.ATRIUM_CAMERA["fov_deg"]), W / H)
+
+    def render(flags, mesh_=mesh, rank=0, n_ranks=1, batch=0, frame=3):
+        pt = PathTracer((W, H), rank=rank, n_ranks=n_ranks)
+        if batch:
+            pt.ctx.set_option(L.OPT_BATCH_SPP, batch)
+        pt.set_scene(mesh_, sky, bn)
+        g = pt.make_gconst(cam, spp, B, frame=frame, flags=flags)
+        pt.render(g)
+        out = pt.light(), pt.gbuffer()[1]
+        st = pt.ctx.stats()
+        pt.close()
+        return out[0], out[1], st, g
+
+    a, depth, st, g = render(SPEC)
+    b = render(SPEC)[0]
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))  # (1)
+    assert st.extension_rays > 1e8 and st.shadow_rays > 5e7
+    merged = np.zeros_like(a)
+    for r in range(4):  # (2)
+        part = render(SPEC, rank=r, n_ranks=4)[0]
+        xy = orc.tile_pixels(W, H, r, 4)
+        merged[xy[:, 1], xy[:, 0]] = part[xy[:, 1], xy[:, 0]]
+    assert np.array_equal(merged.view(np.uint32), a.view(np.uint32))
+    assert np.array_equal(render(SPEC, batch=8)[0].view(np.uint32), a.view(np.uint32))  # (4)
+    bg = depth == L.BACKGROUND_DEPTH
+    assert np.isfinite(a).all() and (a[..., :3] >= 0).all() and (a[bg] == 0).all() and 0.02 < bg.mean() < 0.9  # (5)
+    e1 = render(0)[0]  # (3) reference estimator: emissive only
+    import copy
+    mesh2 = copy.deepcopy(mesh)
+    mesh2.geometries["emission"] *= 2.0
+    e2 = render(0, mesh_=mesh2)[0]
+    assert e1[..., :3].max() > 0 and np.array_equal((e1[..., :3] * 2.0).view(np.uint32), e2[..., :3].view(np.uint32))
+    # (6) oracle on a window in the middle of the frame
+    osc = orc.Scene(mesh, sky, bn)
+    og = as_orc(g)
+    x0, y0 = 928, 508
+    ogb, odepth = osc.gbuffer(og, rect=(x0, y0, x0 + 64, y0 + 64), threads=16)
+    olight, _ = osc.reference_mode(og, ogb, odepth, rect=(x0, y0, x0 + 64, y0 + 64), threads=16)
+    assert np.array_equal(olight[y0:y0 + 64, x0:x0 + 64].view(np.uint32), a[y0:y0 + 64, x0:x0 + 64].view(np.uint32))
