@@ -579,6 +579,11 @@ int rt3_set_option(rt3_ctx* c, int option, int64_t value) {
 // ---- scene
 int rt3_scene_set_vertices(rt3_ctx* c, const float* v, uint32_t n) {
     if (!c || (!v && n)) return fail(c, RT3_E_INVALID, "vertices NULL");
+    // a NaN / infinite position would poison the scene bounds, the Morton codes and every box above it: reject it here
+    // (bounded magnitude too, so that box extents and the quantisation grid cannot overflow to infinity)
+    for (size_t i = 0; i < (size_t)n; i++)
+        for (int k = 0; k < 3; k++)
+            if (!(std::fabs(v[8 * i + k]) <= 1.0e18f)) return fail(c, RT3_E_INVALID, "vertex " + std::to_string(i) + ": position is not finite (or beyond 1e18)");
     HIPC(c, hipSetDevice(c->device));
     if (int r = dev_alloc(c, &c->d_verts, (size_t)n * 8)) return r;
     if (n) HIPC(c, hipMemcpy(c->d_verts, v, (size_t)n * 32, hipMemcpyHostToDevice));

@@ -362,6 +362,12 @@ def test_error_behaviour(small):
     bb = (C.c_uint32 * 2)(i0.value, i1.value)
     assert lib.rt3_pass_launch(ctx.h, b"gbuffer", b"main", 64, 64, 1, C.byref(g), 304, bb, 2) == L.E_STATE
     assert b"texture" in lib.rt3_last_error(ctx.h)
+    # non-finite positions are rejected at upload
+    bad = np.zeros((3, 8), np.float32)
+    bad[1, 2] = np.nan
+    assert lib.rt3_scene_set_vertices(ctx.h, bad.ctypes.data, 3) == L.E_INVALID and b"not finite" in lib.rt3_last_error(ctx.h)
+    bad[1, 2] = np.inf
+    assert lib.rt3_scene_set_vertices(ctx.h, bad.ctypes.data, 3) == L.E_INVALID
     # out-of-range geometry is rejected on the host instead of faulting on the GPU
     gi = mesh.geometries.copy()
     gi["index_offset"][-1] = 2**31
