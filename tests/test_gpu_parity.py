@@ -210,6 +210,21 @@ def test_frame_parity_atrium(small, flags):
     assert np.allclose(color, ocolor, atol=2e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize("spp,bounces", [(1, 1), (3, 1), (2, 2), (1, 6)])
+def test_frame_parity_direct_light_and_depths(small, spp, bounces):
+    """BASELINE configs[1] (1 spp, traversal + direct light only = one bounce with NEE) and other path depths."""
+    mesh, sky, bn, osc = small
+    W, H = 128, 72
+    g, light, gb, depth, color, st = render_both(mesh, sky, bn, osc, W, H, scenes.ATRIUM_CAMERA, spp, bounces, SPEC, frame=1)
+    og = as_orc(g)
+    ogb, odepth = osc.gbuffer(og)
+    olight, counts = osc.reference_mode(og, ogb, odepth)
+    assert np.array_equal(light.view(np.uint32), olight.view(np.uint32))
+    assert st.extension_rays == W * H + int(counts[0]) and st.shadow_rays == int(counts[1])
+    if bounces == 1:
+        assert int(counts[0]) == 0 and st.shadow_rays > 0  # direct light: primary rays + shadow rays only
+
+
 def test_frame_parity_cornell_reference_semantics(cornell):
     """Closed scene: no path ever misses, so the RNG counters coincide with the reference's sequential index++."""
     mesh, osc = cornell
