@@ -44,13 +44,14 @@ def main():
     ap.add_argument("--node-width", type=int, default=0, help="2 | 4 (0 = library default)")
     ap.add_argument("--node-quant", type=int, default=-1, help="0 | 1 (-1 = library default)")
     ap.add_argument("--refill", type=int, default=-1, help="traversal tuning: idle lanes before a wave refills (RT3_OPT_EXTEND_VARIANT)")
+    ap.add_argument("--pool-chunk", type=int, default=0, help="traversal tuning: rays per pool grab (RT3_OPT_POOL_CHUNK)")
     ap.add_argument("--flags", type=int, default=-1, help="GConst.pad[0] feature flags (-1 = the full estimator); experiments only")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-crop", type=str, default="960x540")
     args = ap.parse_args()
     default_workload = (args.gpus == 1 and (args.width, args.height, args.spp, args.bounces, args.detail) == (1920, 1080, 64, 4, 1.0)
                         and args.batch_spp == 0 and args.leaf_size == 0 and args.node_width == 0 and args.node_quant == -1
-                        and args.refill == -1 and args.flags == -1)
+                        and args.refill == -1 and args.flags == -1 and args.pool_chunk == 0)
 
     import numpy as np
     import torch
@@ -94,6 +95,8 @@ def main():
         pt.ctx.set_option(L.OPT_NODE_QUANT, args.node_quant)
     if args.refill >= 0:
         pt.ctx.set_option(L.OPT_EXTEND_VARIANT, args.refill)
+    if args.pool_chunk:
+        pt.ctx.set_option(L.OPT_POOL_CHUNK, args.pool_chunk)
     pt.set_scene(mesh, sky, bn)
     if args.batch_spp:
         pt.ctx.set_option(L.OPT_BATCH_SPP, args.batch_spp)

@@ -114,6 +114,7 @@ int rt3_device_name(rt3_ctx *ctx, char *buf, size_t buf_size);
 #define RT3_OPT_NODE_WIDTH 6      /* 2 = binary nodes, 4 = four-wide nodes (default); next rt3_accel_build */
 #define RT3_OPT_NODE_QUANT 7      /* width 4 only: 1 = 64 B nodes with 8-bit conservative child boxes (default), 0 = 128 B fp32 boxes, 2 = compact 48 B nodes (implied references) */
 #define RT3_OPT_WIDE_COLLAPSE 8   /* width 4 only: how binary LBVH nodes are grouped into four-wide nodes: 1 = by surface area (default), 0 = even binary depth */
+#define RT3_OPT_POOL_CHUNK 9      /* traversal tuning: rays a wave takes from the launch's ray pool per grab (default 256) */
 int rt3_set_option(rt3_ctx *ctx, int option, int64_t value);
 
 /* ---- scene upload: DynamicBuffer::push (vulkan/buffer.rs:406-420) into the world buffers of

@@ -564,6 +564,10 @@ int rt3_set_option(rt3_ctx* c, int option, int64_t value) {
             c->opt_node_quant = (uint32_t)value;
             c->accel_built = false;
             return RT3_OK;
+        case RT3_OPT_POOL_CHUNK:
+            if (value < 64 || value > 65536 || (value & 63)) return fail(c, RT3_E_INVALID, "pool chunk must be a multiple of 64 in [64, 65536]");
+            set_pool_chunk((uint32_t)value);
+            return RT3_OK;
         case RT3_OPT_WIDE_COLLAPSE:
             if (value != 0 && value != 1) return fail(c, RT3_E_INVALID, "wide collapse must be 0 (even depth) or 1 (surface area)");
             c->opt_collapse = (uint32_t)value;

@@ -71,6 +71,7 @@ void launch_pack_tiles(hipStream_t st, const uint32_t* pixels, uint32_t npix, ui
 void launch_unpack_tiles(hipStream_t st, const uint32_t* pixels, uint32_t npix, uint32_t width, const void* src, void* img);
 
 void set_refill_lanes(uint32_t v);
+void set_pool_chunk(uint32_t v);
 bool selftest_widths(int op, uint32_t* in_w, uint32_t* out_w);
 void launch_selftest(hipStream_t st, int op, const uint32_t* in, uint32_t n, uint32_t* out);
 

@@ -75,9 +75,10 @@ __device__ __forceinline__ void tri_test_nb(float4 q0, float4 q1, float4 q2, V3 
 // Every step makes exactly ONE memory round trip: a lane first fetches its next item -- the node, or the next
 // triangle(s) of its current leaf -- with one batch of 16-byte loads issued together, then branches into box or
 // triangle tests (both branch-free).
-constexpr uint32_t kPoolChunk = 256;
+__constant__ uint32_t g_pool_chunk = 256;   // rays per pool grab (RT3_OPT_POOL_CHUNK)
 __constant__ uint32_t g_refill_lanes = 12;  // tuning knob (RT3_OPT_EXTEND_VARIANT)
 void set_refill_lanes(uint32_t v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_refill_lanes), &v, 4); }
+void set_pool_chunk(uint32_t v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pool_chunk), &v, 4); }
 
 struct LaneRay {  // traversal state of the ray a lane currently owns
     V3 o, d, inv;
@@ -102,7 +103,12 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
     bool queue_empty = false;
     const uint32_t lane = __lane_id();
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
-    const uint32_t kRefillLanes = g_refill_lanes;
+    const uint32_t kRefillLanes = g_refill_lanes, kPoolChunk = g_pool_chunk;
+    // the first chunk of every wave is static (chunk number = global wave number): no atomic storm at launch, when all the
+    // waves of the grid would hit the cursor at once (8192 returning atomics on one word ~ 0.1 ms); the cursor counts the
+    // chunks handed out after those
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6), wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    bool first_chunk = true;
     uint32_t spill[kSpill];
     LaneRay r;
     r.o = r.d = r.inv = v3(0.0f, 0.0f, 0.0f);
@@ -116,11 +122,18 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
         const unsigned long long m_idle = __ballot(!busy);
         if (pool_next >= pool_end && !queue_empty && m_idle != 0ull) {  // grab the next chunk (wave-uniform)
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(work_counter, kPoolChunk);
-            base = __builtin_amdgcn_readfirstlane(base);
+            if (first_chunk) {
+                base = wave_id * kPoolChunk;
+                first_chunk = false;
+            } else {
+                if (lane == 0) base = atomicAdd(work_counter, kPoolChunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                const unsigned long long b64 = (unsigned long long)n_waves * kPoolChunk + base;  // may exceed 2^32 only past the end
+                base = b64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)b64;
+            }
             queue_empty = base >= n;
             pool_next = base < n ? base : n;
-            pool_end = base + kPoolChunk < n ? base + kPoolChunk : n;
+            pool_end = (n - pool_next) > kPoolChunk ? pool_next + kPoolChunk : n;
         }
         if (m_idle != 0ull && pool_next < pool_end && ((uint32_t)__popcll(m_idle) >= kRefillLanes || m_idle == ~0ull)) {
             const uint32_t idx = pool_next + (uint32_t)__popcll(m_idle & lanes_below);
