@@ -8,8 +8,9 @@ value = Mrays/s = (primary + bounce + shadow rays of all ranks) / max-over-ranks
 Strong scaling: the frame is fixed, tiles are split over the ranks.
 
 Extra objects on the JSON line:
-  roofline     k_extend: algorithmic bytes (48 + 64 n_nodes + 48 n_tris per ray) / HIP-event time
-               of the k_extend launches inside the timed region, against the 8 TB/s HBM3E peak
+  roofline     the dominant kernel -- k_extend on one GPU; k_trace (extension queue then shadow queue in one launch, used
+               when the frame is split and launches are short) otherwise: algorithmic bytes (48 + 64 n_nodes + 48 n_tris
+               per ray) / HIP-event time of its launches inside the timed region, against the 8 TB/s HBM3E peak
   cpu_baseline the CPU oracle (a port; the reference cannot be built here) path tracing a centred crop of the same
                frame on the host cores; the crop also yields rmse_vs_oracle
 """
@@ -44,6 +45,7 @@ def main():
     ap.add_argument("--node-width", type=int, default=0, help="2 | 4 (0 = library default)")
     ap.add_argument("--node-quant", type=int, default=-1, help="0 | 1 (-1 = library default)")
     ap.add_argument("--refill", type=int, default=-1, help="traversal tuning: idle lanes before a wave refills (RT3_OPT_EXTEND_VARIANT)")
+    ap.add_argument("--fused-trace", type=int, default=-1, help="RT3_OPT_FUSED_TRACE: 1 one k_trace launch per bounce, 0 separate k_shadow / k_extend, -1 library default (by launch size)")
     ap.add_argument("--pool-chunk", type=int, default=0, help="traversal tuning: rays per pool grab (RT3_OPT_POOL_CHUNK)")
     ap.add_argument("--flags", type=int, default=-1, help="GConst.pad[0] feature flags (-1 = the full estimator); experiments only")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -51,7 +53,7 @@ def main():
     args = ap.parse_args()
     default_workload = (args.gpus == 1 and (args.width, args.height, args.spp, args.bounces, args.detail) == (1920, 1080, 64, 4, 1.0)
                         and args.batch_spp == 0 and args.leaf_size == 0 and args.node_width == 0 and args.node_quant == -1
-                        and args.refill == -1 and args.flags == -1 and args.pool_chunk == 0)
+                        and args.refill == -1 and args.flags == -1 and args.pool_chunk == 0 and args.fused_trace == -1)
 
     import numpy as np
     import torch
@@ -97,6 +99,8 @@ def main():
         pt.ctx.set_option(L.OPT_EXTEND_VARIANT, args.refill)
     if args.pool_chunk:
         pt.ctx.set_option(L.OPT_POOL_CHUNK, args.pool_chunk)
+    if args.fused_trace >= 0:
+        pt.ctx.set_option(L.OPT_FUSED_TRACE, args.fused_trace)
     pt.set_scene(mesh, sky, bn)
     if args.batch_spp:
         pt.ctx.set_option(L.OPT_BATCH_SPP, args.batch_spp)
@@ -138,20 +142,31 @@ def main():
     else:
         rays_total, ext_total, sh_total = float(rays_local), float(st.extension_rays), float(st.shadow_rays)
 
-    # ---- roofline of the dominant kernel (k_extend) on this rank: one untimed counting frame gives n_nodes / n_tris
+    # ---- roofline of the dominant kernel on this rank: one untimed counting frame gives n_nodes / n_tris
     pt.ctx.set_option(L.OPT_COUNT_TRAVERSAL, 1)
     pt.ctx.stats_reset()
     pt.render(g_last, postprocess=False, wait=True)
     cst = pt.ctx.stats()
     pt.ctx.set_option(L.OPT_COUNT_TRAVERSAL, 0)
     n_nodes, n_tris, levels, node_bytes = pt.ctx.accel_info()
-    bytes_per_frame = 48.0 * cst.extension_rays + float(node_bytes) * cst.nodes_visited + 48.0 * cst.tris_tested
-    sh_bytes_per_frame = 48.0 * cst.shadow_rays + float(node_bytes) * cst.shadow_nodes_visited + 48.0 * cst.shadow_tris_tested
-    ext_ms_per_frame = st.extend_ms / max(args.steps, 1)
-    launches_per_frame = st.extend_launches / max(args.steps, 1)
-    achieved = bytes_per_frame / (ext_ms_per_frame * 1e-3) / 1e9 if ext_ms_per_frame > 0 else 0.0
+    steps = max(args.steps, 1)
+    nb = float(node_bytes)
+    ext_bytes = 48.0 * cst.extension_rays + nb * cst.nodes_visited + 48.0 * cst.tris_tested          # all closest-hit rays of the frame
+    sh_bytes = 48.0 * cst.shadow_rays + nb * cst.shadow_nodes_visited + 48.0 * cst.shadow_tris_tested  # all any-hit rays
+    # the dominant kernel: k_trace (one launch per bounce, extension queue then shadow queue) when the fused path is on,
+    # k_extend otherwise.  Its algorithmic bytes come from its own counters of the counting frame.
+    fused = st.trace_launches > 0
+    if fused:
+        dom_name = "k_trace"
+        dom_rays = float(cst.trace_rays[0] + cst.trace_rays[1])
+        dom_bytes = 48.0 * dom_rays + nb * (cst.trace_nodes[0] + cst.trace_nodes[1]) + 48.0 * (cst.trace_tris[0] + cst.trace_tris[1])
+        dom_ms, dom_launches = st.trace_ms / steps, st.trace_launches / steps
+    else:
+        dom_name, dom_rays, dom_bytes, dom_ms, dom_launches = "k_extend", float(cst.extension_rays), ext_bytes, st.extend_ms / steps, st.extend_launches / steps
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    trav_ms = (st.trace_ms + st.extend_ms + st.shadow_ms) / steps  # every traversal launch of the frame
     peak = 8000.0
-    # HBM-side bytes per k_extend launch cannot be counted from inside this process: they come from separate
+    # HBM-side bytes per launch cannot be counted from inside this process: they come from separate
     # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command (tools/profile_round.sh), corrected as
     # MI355X_MICROARCH.md prescribes by tools/summarize_profile.py and committed under profiles/. Only quoted for the
     # default workload they were collected on; null otherwise.
@@ -159,22 +174,24 @@ def main():
     tfiles = sorted((ROOT / "profiles").glob("*_traffic.json"))
     if tfiles and default_workload:
         tj = json.loads(tfiles[-1].read_text())
-        kk = [v for k, v in tj["kernels"].items() if k.startswith("rt3::k_extend<false")]
+        kk = [v for k, v in tj["kernels"].items() if k.startswith(f"rt3::{dom_name}<false")]
         if kk:
             traffic = round(kk[0]["hbm_bytes_per_launch"])
             traffic_src = f"profiles/{tfiles[-1].name}: {tj['correction']}"
     roofline = {
-        "kernel": "k_extend", "bound": "hbm", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s", "frac": round(achieved / peak, 4),
+        "kernel": dom_name, "bound": "hbm", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s", "frac": round(achieved / peak, 4),
         "traffic": traffic, "traffic_source": traffic_src,
-        "launches_per_frame": launches_per_frame, "avg_launch_ms": round(ext_ms_per_frame / max(launches_per_frame, 1), 4),
-        "algorithmic_bytes_per_launch": round(bytes_per_frame / max(launches_per_frame, 1)),
+        "launches_per_frame": dom_launches, "avg_launch_ms": round(dom_ms / max(dom_launches, 1), 4),
+        "algorithmic_bytes_per_launch": round(dom_bytes / max(dom_launches, 1)), "rays_per_launch": round(dom_rays / max(dom_launches, 1)),
         "bytes_per_ray_formula": f"48 + {node_bytes}*n_nodes + 48*n_tris", "bvh": {"nodes": n_nodes, "node_bytes": node_bytes, "tris": n_tris, "levels": levels},
         "rays_per_frame": int(cst.extension_rays), "nodes_per_ray": round(cst.nodes_visited / max(cst.extension_rays, 1), 2),
         "tris_per_ray": round(cst.tris_tested / max(cst.extension_rays, 1), 2),
-        "k_shadow": {"achieved": round(sh_bytes_per_frame / max(st.shadow_ms / max(args.steps, 1) * 1e-3, 1e-12) / 1e9, 1),
-                     "rays_per_frame": int(cst.shadow_rays), "ms_per_frame": round(st.shadow_ms / max(args.steps, 1), 3)},
-        "ms_per_frame": {"k_extend": round(ext_ms_per_frame, 3), "k_shadow": round(st.shadow_ms / max(args.steps, 1), 3),
-                         "k_shade": round(st.shade_ms / max(args.steps, 1), 3), "other": round(st.other_ms / max(args.steps, 1), 3)},
+        "shadow": {"rays_per_frame": int(cst.shadow_rays), "nodes_per_ray": round(cst.shadow_nodes_visited / max(cst.shadow_rays, 1), 2),
+                   "tris_per_ray": round(cst.shadow_tris_tested / max(cst.shadow_rays, 1), 2)},
+        "all_traversal": {"achieved": round((ext_bytes + sh_bytes) / max(trav_ms * 1e-3, 1e-12) / 1e9, 1), "ms_per_frame": round(trav_ms, 3),
+                          "launches_per_frame": (st.trace_launches + st.extend_launches + st.shadow_launches) / steps},
+        "ms_per_frame": {"k_trace": round(st.trace_ms / steps, 3), "k_extend": round(st.extend_ms / steps, 3), "k_shadow": round(st.shadow_ms / steps, 3),
+                         "k_shade": round(st.shade_ms / steps, 3), "other": round(st.other_ms / steps, 3)},
     }
 
     out = {

@@ -95,6 +95,13 @@ typedef struct rt3_stats {
     double shadow_ms;
     double shade_ms;
     double other_ms;
+    /* k_trace = one launch per bounce that drains the extension queue and then the shadow queue (the frame's dominant
+     * kernel); its rays are ALSO included in extension_rays / shadow_rays and its visits in the four totals above */
+    uint64_t trace_launches;
+    double trace_ms;
+    uint64_t trace_rays[2];  /* counting mode: [0] closest-hit, [1] any-hit rays traced by k_trace launches */
+    uint64_t trace_nodes[2];
+    uint64_t trace_tris[2];
 } rt3_stats;
 
 typedef struct rt3_ctx rt3_ctx;
@@ -115,6 +122,8 @@ int rt3_device_name(rt3_ctx *ctx, char *buf, size_t buf_size);
 #define RT3_OPT_NODE_QUANT 7      /* width 4 only: 1 = 64 B nodes with 8-bit conservative child boxes (default), 0 = 128 B fp32 boxes, 2 = compact 48 B nodes (implied references) */
 #define RT3_OPT_WIDE_COLLAPSE 8   /* width 4 only: how binary LBVH nodes are grouped into four-wide nodes: 1 = by surface area (default), 0 = even binary depth */
 #define RT3_OPT_POOL_CHUNK 9      /* traversal tuning: rays a wave takes from the launch's ray pool per grab (default 256) */
+#define RT3_OPT_FUSED_TRACE 10    /* 1: one k_trace launch per bounce for extension + shadow rays; 0: separate k_shadow and k_extend launches;
+                                     -1 (default): fused for batches of at most 24 Mi paths, where launches are short */
 int rt3_set_option(rt3_ctx *ctx, int option, int64_t value);
 
 /* ---- scene upload: DynamicBuffer::push (vulkan/buffer.rs:406-420) into the world buffers of

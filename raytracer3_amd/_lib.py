@@ -17,7 +17,7 @@ BACKGROUND_DEPTH = 100000.0
 FORMAT_R32_SFLOAT, FORMAT_R32G32B32A32_SFLOAT, FORMAT_R32G32B32A32_UINT, FORMAT_R8G8B8A8_UNORM = 100, 109, 107, 37
 F_NEE_SKY, F_BLUENOISE, F_SPECULAR, F_FACEFORWARD = 1, 2, 4, 8
 OPT_BATCH_SPP, OPT_PROFILE, OPT_COUNT_TRAVERSAL, OPT_EXTEND_VARIANT, OPT_LEAF_SIZE, OPT_NODE_WIDTH, OPT_NODE_QUANT = 1, 2, 3, 4, 5, 6, 7
-OPT_WIDE_COLLAPSE, OPT_POOL_CHUNK = 8, 9
+OPT_WIDE_COLLAPSE, OPT_POOL_CHUNK, OPT_FUSED_TRACE = 8, 9, 10
 
 EXPORTS = [
     "rt3_create", "rt3_destroy", "rt3_last_error", "rt3_device_name", "rt3_set_option",
@@ -41,7 +41,9 @@ class Stats(C.Structure):
     _fields_ = [("extension_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("nodes_visited", C.c_uint64), ("tris_tested", C.c_uint64),
                 ("shadow_nodes_visited", C.c_uint64), ("shadow_tris_tested", C.c_uint64),
                 ("extend_launches", C.c_uint64), ("extend_ms", C.c_double), ("shadow_launches", C.c_uint64), ("shadow_ms", C.c_double),
-                ("shade_ms", C.c_double), ("other_ms", C.c_double)]
+                ("shade_ms", C.c_double), ("other_ms", C.c_double),
+                ("trace_launches", C.c_uint64), ("trace_ms", C.c_double), ("trace_rays", C.c_uint64 * 2), ("trace_nodes", C.c_uint64 * 2),
+                ("trace_tris", C.c_uint64 * 2)]
 
 
 assert C.sizeof(GConst) == 304

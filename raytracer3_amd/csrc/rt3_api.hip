@@ -36,7 +36,7 @@ struct PixelList {
     uint32_t w, h, rank, n_ranks, count;
     uint32_t* dev;
 };
-enum Cat { CAT_EXTEND = 0, CAT_SHADOW = 1, CAT_SHADE = 2, CAT_OTHER = 3 };
+enum Cat { CAT_EXTEND = 0, CAT_SHADOW = 1, CAT_SHADE = 2, CAT_OTHER = 3, CAT_TRACE = 4 };
 struct Timed {
     hipEvent_t a, b;
     int cat;
@@ -95,6 +95,7 @@ struct rt3_ctx {
     bool opt_profile = false, opt_count = false;
     int opt_variant = 0;  // RT3_OPT_EXTEND_VARIANT: reserved for traversal experiments
     uint32_t opt_leaf_size = 2, opt_node_width = 4, opt_node_quant = 1, opt_collapse = 1;
+    int opt_fused_trace = -1;  // -1 auto (by launch size), 0 off, 1 on
     rt3_stats stats;
     uint64_t primary_rays_pending = 0;
     std::vector<Timed> pending_events;
@@ -279,13 +280,19 @@ int harvest(rt3_ctx* c) {  // stream must be idle
     c->stats.extension_rays += c->primary_rays_pending;
     c->primary_rays_pending = 0;
     if (c->opt_count) {
-        unsigned long long t[4] = {0, 0, 0, 0};
-        HIPC(c, hipMemcpy(t, c->d_totals, 32, hipMemcpyDeviceToHost));
-        c->stats.nodes_visited += t[0];
-        c->stats.tris_tested += t[1];
-        c->stats.shadow_nodes_visited += t[2];
-        c->stats.shadow_tris_tested += t[3];
-        HIPC(c, hipMemset(c->d_totals, 0, 32));
+        unsigned long long t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [0..3] k_extend / k_shadow, [4..9] k_trace {rays, nodes, tris} x 2
+        HIPC(c, hipMemcpy(t, c->d_totals, sizeof(t), hipMemcpyDeviceToHost));
+        c->stats.nodes_visited += t[0] + t[5];
+        c->stats.tris_tested += t[1] + t[6];
+        c->stats.shadow_nodes_visited += t[2] + t[8];
+        c->stats.shadow_tris_tested += t[3] + t[9];
+        c->stats.trace_rays[0] += t[4];
+        c->stats.trace_nodes[0] += t[5];
+        c->stats.trace_tris[0] += t[6];
+        c->stats.trace_rays[1] += t[7];
+        c->stats.trace_nodes[1] += t[8];
+        c->stats.trace_tris[1] += t[9];
+        HIPC(c, hipMemset(c->d_totals, 0, sizeof(t)));
     }
     for (auto& t : c->pending_events) {
         float ms = 0.0f;
@@ -294,6 +301,7 @@ int harvest(rt3_ctx* c) {  // stream must be idle
             case CAT_EXTEND: c->stats.extend_ms += ms; c->stats.extend_launches++; break;
             case CAT_SHADOW: c->stats.shadow_ms += ms; c->stats.shadow_launches++; break;
             case CAT_SHADE: c->stats.shade_ms += ms; break;
+            case CAT_TRACE: c->stats.trace_ms += ms; c->stats.trace_launches++; break;
             default: c->stats.other_ms += ms; break;
         }
         c->free_events.push_back(t);
@@ -445,15 +453,24 @@ int pass_reference_mode(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y,
                 launch_shade(c->stream, bn == 0, L);
             }
             cur ^= 1;
-            if (nee) {
-                ScopedTimer t(c, CAT_SHADOW);
-                launch_shadow(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->sh_rays, S, sh_cnt + bn, 0, n_first, c->sh_contrib, c->sh_pid,
-                              c->lacc, S, nullptr, nullptr, nullptr, c->opt_count ? c->d_totals + 2 : nullptr, pool_cur + B + bn);
-            }
-            if (bn != B - 1) {
-                ScopedTimer t(c, CAT_EXTEND);
-                launch_extend(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->rays[cur], S, ext_cnt + bn, 0, n_first, c->hits, nullptr, nullptr,
-                              c->opt_count ? c->d_totals : nullptr, pool_cur + bn);
+            // both queues in one launch: one machine-wide drain less per bounce.  It pays when launches are short (a frame split over
+            // 8 GPUs: -1.7 %) and costs 2 % on the single-GPU frame, where each launch runs for > 10 ms: decided by the batch size
+            const bool fuse = c->opt_fused_trace == 1 || (c->opt_fused_trace < 0 && n_first <= (24u << 20));
+            if (nee && bn != B - 1 && fuse) {
+                ScopedTimer t(c, CAT_TRACE);
+                launch_trace(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->rays[cur], c->sh_rays, S, ext_cnt + bn, sh_cnt + bn, n_first,
+                             c->hits, c->sh_contrib, c->lacc, c->opt_count ? c->d_totals + 4 : nullptr, pool_cur + bn, pool_cur + B + bn);
+            } else {
+                if (nee) {
+                    ScopedTimer t(c, CAT_SHADOW);
+                    launch_shadow(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->sh_rays, S, sh_cnt + bn, 0, n_first, c->sh_contrib, c->sh_pid,
+                                  c->lacc, S, nullptr, nullptr, nullptr, c->opt_count ? c->d_totals + 2 : nullptr, pool_cur + B + bn);
+                }
+                if (bn != B - 1) {
+                    ScopedTimer t(c, CAT_EXTEND);
+                    launch_extend(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->rays[cur], S, ext_cnt + bn, 0, n_first, c->hits, nullptr, nullptr,
+                                  c->opt_count ? c->d_totals : nullptr, pool_cur + bn);
+                }
             }
         }
         {
@@ -508,7 +525,7 @@ int rt3_create(int device, rt3_ctx** out) {
     snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
     memset(&c->stats, 0, sizeof(c->stats));
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&c->d_counters, (size_t)c->counters_cap * 4) != hipSuccess ||
-        hipMalloc((void**)&c->d_totals, 32) != hipSuccess || hipMemset(c->d_totals, 0, 32) != hipSuccess) {
+        hipMalloc((void**)&c->d_totals, 80) != hipSuccess || hipMemset(c->d_totals, 0, 80) != hipSuccess) {
         delete c;
         return fail(nullptr, RT3_E_HIP, "stream / counter allocation failed");
     }
@@ -563,6 +580,10 @@ int rt3_set_option(rt3_ctx* c, int option, int64_t value) {
             if (value < 0 || value > 2) return fail(c, RT3_E_INVALID, "node quantisation must be 0 (fp32), 1 (64 B) or 2 (compact 48 B)");
             c->opt_node_quant = (uint32_t)value;
             c->accel_built = false;
+            return RT3_OK;
+        case RT3_OPT_FUSED_TRACE:
+            if (value < -1 || value > 1) return fail(c, RT3_E_INVALID, "fused trace must be -1 (auto), 0 or 1");
+            c->opt_fused_trace = (int)value;
             return RT3_OK;
         case RT3_OPT_POOL_CHUNK:
             if (value < 64 || value > 65536 || (value & 63)) return fail(c, RT3_E_INVALID, "pool chunk must be a multiple of 64 in [64, 65536]");

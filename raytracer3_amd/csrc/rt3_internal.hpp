@@ -59,6 +59,9 @@ void launch_extend(hipStream_t st, bool count, int layout, const float4* nodes, 
 void launch_shadow(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float* rays, size_t stride,
                    const uint32_t* count_ptr, uint32_t count_imm, uint32_t max_n, const float* contrib, const uint32_t* pid, float* lacc,
                    size_t lstride, uint32_t* occluded_out, uint32_t* cn, uint32_t* ct, unsigned long long* totals, uint32_t* work_counter);
+void launch_trace(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float* ext_rays, const float* sh_rays,
+                  size_t stride, const uint32_t* ext_count, const uint32_t* sh_count, uint32_t max_n, float* hits, const float* contrib, float* lacc,
+                  unsigned long long* totals, uint32_t* work_ext, uint32_t* work_sh);
 void launch_gbuffer(hipStream_t st, const SceneDev& sc, const uint32_t* pixels, uint32_t npix, uint32_t width, const float* hits,
                     size_t stride, void* gbuffer, float* depth);
 void launch_shade(hipStream_t st, bool first, const ShadeLaunch& L);

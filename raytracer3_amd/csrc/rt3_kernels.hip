@@ -399,6 +399,51 @@ __global__ __launch_bounds__(kExtendBlock) void k_shadow(const float4* __restric
     }
 }
 
+// One launch per bounce for BOTH ray kinds: every wave first helps to drain the extension queue (closest hit), then the
+// shadow queue (any hit), without a grid-wide barrier in between -- a launch boundary idles the machine while the last
+// waves finish (each k_extend / k_shadow pair cost one such drain more), which matters most when the frame is split
+// over several GPUs and every launch is 1/N as long.  totals (counting mode): {rays, nodes, tris} x {closest, any}.
+template <bool COUNT, int LAYOUT>
+__global__ __launch_bounds__(kExtendBlock) void k_trace(const float4* __restrict__ nodes, const float4* __restrict__ tris,
+                                                        const float* __restrict__ ext_rays, const float* __restrict__ sh_rays, size_t stride,
+                                                        const uint32_t* __restrict__ ext_count, const uint32_t* __restrict__ sh_count,
+                                                        float* __restrict__ hits, const float* __restrict__ contrib, float* __restrict__ lacc,
+                                                        unsigned long long* __restrict__ totals, uint32_t* __restrict__ work_ext,
+                                                        uint32_t* __restrict__ work_sh) {
+    __shared__ uint32_t stack[kLdsStack * kExtendBlock];
+    const uint32_t n_ext = *ext_count, n_sh = *sh_count;
+    unsigned long long en = 0, et = 0, sn = 0, stt = 0;
+    trace_stream<false, COUNT, LAYOUT>(nodes, tris, ext_rays, stride, n_ext, work_ext, stack + threadIdx.x, [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct) {
+        reinterpret_cast<float4*>(hits)[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
+        if (COUNT) {
+            en += cn;
+            et += ct;
+        }
+    });
+    trace_stream<true, COUNT, LAYOUT>(nodes, tris, sh_rays, stride, n_sh, work_sh, stack + threadIdx.x, [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct) {
+        if (h.prim == kMiss) {
+            const float4 c = reinterpret_cast<const float4*>(contrib)[i];  // {rgb, path id}
+            float4* L = reinterpret_cast<float4*>(lacc) + __float_as_uint(c.w);
+            float4 v = *L;
+            *L = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, 0.0f);
+        }
+        if (COUNT) {
+            sn += cn;
+            stt += ct;
+        }
+    });
+    if (COUNT && totals) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            atomicAdd(&totals[0], (unsigned long long)n_ext);
+            atomicAdd(&totals[3], (unsigned long long)n_sh);
+        }
+        atomicAdd(&totals[1], en);
+        atomicAdd(&totals[2], et);
+        atomicAdd(&totals[4], sn);
+        atomicAdd(&totals[5], stt);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ gbuffer pass
 // gbuffer.slang:8-12 : primary rays for the pixels this rank owns (pixel list is in tile / Z-curve order)
 __global__ void k_raygen(GConstDev g, const uint32_t* __restrict__ pixels, uint32_t npix, float* __restrict__ rays, size_t stride) {
@@ -903,6 +948,26 @@ void launch_shadow(hipStream_t st, bool count, int layout, const float4* nodes, 
         else RT3_LAUNCH_SHADOW(false, kLayoutBinary64);
     }
 #undef RT3_LAUNCH_SHADOW
+}
+void launch_trace(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float* ext_rays, const float* sh_rays,
+                  size_t stride, const uint32_t* ext_count, const uint32_t* sh_count, uint32_t max_n, float* hits, const float* contrib, float* lacc,
+                  unsigned long long* totals, uint32_t* work_ext, uint32_t* work_sh) {
+    unsigned grid = grid_for(max_n, kExtendBlock, kExtendMaxBlocks);
+#define RT3_LAUNCH_TRACE(C, L)                                                                                                                  \
+    hipLaunchKernelGGL((k_trace<C, L>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, ext_rays, sh_rays, stride, ext_count, sh_count, hits, \
+                       contrib, lacc, totals, work_ext, work_sh)
+    if (count) {
+        if (layout == kLayoutWide48Q) RT3_LAUNCH_TRACE(true, kLayoutWide48Q);
+        else if (layout == kLayoutWide64Q) RT3_LAUNCH_TRACE(true, kLayoutWide64Q);
+        else if (layout == kLayoutWide128) RT3_LAUNCH_TRACE(true, kLayoutWide128);
+        else RT3_LAUNCH_TRACE(true, kLayoutBinary64);
+    } else {
+        if (layout == kLayoutWide48Q) RT3_LAUNCH_TRACE(false, kLayoutWide48Q);
+        else if (layout == kLayoutWide64Q) RT3_LAUNCH_TRACE(false, kLayoutWide64Q);
+        else if (layout == kLayoutWide128) RT3_LAUNCH_TRACE(false, kLayoutWide128);
+        else RT3_LAUNCH_TRACE(false, kLayoutBinary64);
+    }
+#undef RT3_LAUNCH_TRACE
 }
 void launch_gbuffer(hipStream_t st, const SceneDev& sc, const uint32_t* pixels, uint32_t npix, uint32_t width, const float* hits,
                     size_t stride, void* gbuffer, float* depth) {

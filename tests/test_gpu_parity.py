@@ -504,3 +504,29 @@ def test_full_size_frame_properties():
     ogb, odepth = osc.gbuffer(og, rect=(x0, y0, x0 + 64, y0 + 64), threads=16)
     olight, _ = osc.reference_mode(og, ogb, odepth, rect=(x0, y0, x0 + 64, y0 + 64), threads=16)
     assert np.array_equal(olight[y0:y0 + 64, x0:x0 + 64].view(np.uint32), a[y0:y0 + 64, x0:x0 + 64].view(np.uint32))
+
+
+def test_fused_and_separate_traversal_launches_agree(small):
+    """RT3_OPT_FUSED_TRACE: one k_trace launch per bounce (extension queue, then shadow queue) vs k_shadow + k_extend: same
+    image, same ray counts, same traversal counters; k_trace's own counters cover exactly its launches."""
+    mesh, sky, bn, osc = small
+    W, H = 128, 72
+    out = {}
+    for fused in (0, 1):
+        pt = PathTracer((W, H))
+        pt.ctx.set_option(L.OPT_FUSED_TRACE, fused)
+        pt.ctx.set_option(L.OPT_COUNT_TRAVERSAL, 1)
+        pt.set_scene(mesh, sky, bn)
+        cam = Camera(scenes.ATRIUM_CAMERA["position"], scenes.ATRIUM_CAMERA["direction"], math.radians(65.0), W / H)
+        g = pt.make_gconst(cam, 4, 4, frame=2, flags=SPEC)
+        pt.ctx.set_option(L.OPT_PROFILE, 1)
+        pt.render(g)
+        out[fused] = (pt.light(), pt.ctx.stats())
+        pt.close()
+    (la, sa), (lb, sb) = out[0], out[1]
+    assert np.array_equal(la.view(np.uint32), lb.view(np.uint32))
+    for f in ("extension_rays", "shadow_rays", "nodes_visited", "tris_tested", "shadow_nodes_visited", "shadow_tris_tested"):
+        assert getattr(sa, f) == getattr(sb, f) > 0, f
+    assert sa.trace_launches == 0 and sb.trace_launches == 3 and sb.extend_launches == 1 and sb.shadow_launches == 1
+    assert sb.trace_rays[0] == sb.extension_rays - W * H  # every bounce ray, not the primary rays of the gbuffer pass
+    assert 0 < sb.trace_rays[1] < sb.shadow_rays and 0 < sb.trace_nodes[0] < sb.nodes_visited and 0 < sb.trace_nodes[1] < sb.shadow_nodes_visited
