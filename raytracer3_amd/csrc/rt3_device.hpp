@@ -486,16 +486,7 @@ RT3_DEV V3 sky_eval_and_pdf(const SceneDev& sc, float u, float v, float& pdf) {
     pdf = st > 0.0f ? pt / (2.0f * kPi * kPi * st) : 0.0f;
     return rad;
 }
-RT3_DEV uint32_t cdf_find(const float* cdf, uint32_t n, float u) {  // first index with cdf[i] > u
-    uint32_t lo = 0, hi = n - 1;
-    while (lo < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (cdf[mid] > u) hi = mid;
-        else lo = mid + 1;
-    }
-    return lo;
-}
-// Same index as cdf_find (first i with cdf[i] > u) plus the bracket {cdf[i-1] (0 for i = 0), cdf[i]}, in two memory
+// The oracle's cdf_find -- first i with cdf[i] > u -- plus the bracket {cdf[i-1] (0 for i = 0), cdf[i]}, in two memory
 // round trips: the guide cell of u gives bounds [lo, hi] around the answer; when they are at most two apart (81-93 % of
 // the lookups on the bench sky) ONE unaligned 16-byte load {cdf[lo-1] .. cdf[lo+2]} of the padded CDF holds every
 // candidate and the bracket.  Wider cells fall back to the binary search.  These gathers are what k_shade is bound by.

@@ -19,10 +19,7 @@ constexpr unsigned kExtendMaxBlocks = 2048;  // 256 CUs x 8: grid-stride beyond 
 constexpr int kLayoutBinary64 = 0;   // 64 B: two fp32 child boxes + two references
 constexpr int kLayoutWide128 = 1;    // 128 B: four {fp32 min, max, ref, pad} slots
 constexpr int kLayoutWide48Q = 3;    // 48 B: as kLayoutWide64Q, references implied (node_base / tri_base + a nibble per child): 3 loads per node
-#ifndef RT3_C48_STRIDE
-#define RT3_C48_STRIDE 3
-#endif
-constexpr int kC48Stride = RT3_C48_STRIDE;  // float4s between consecutive compact nodes (experiment: 4 = padded to 64 B)
+constexpr int kC48Stride = 3;        // float4s per compact node
 constexpr int kLayoutWide64Q = 2;    // 64 B: origin + power-of-two steps + four 8-bit boxes + four references
 constexpr uint32_t kMaxStack = 64;         // traversal stack entries: LDS short stack (20) + private spill (44)
 

@@ -18,10 +18,7 @@ namespace rt3 {
 // ------------------------------------------------------------------------------------------------ traversal
 // One ray per lane.  Short stack: kLdsStack entries per lane in LDS ([entry][lane] so a wave's ds_read_b32 /
 // ds_write_b32 hit 64 consecutive dwords: conflict-free), deeper entries spill to a private array (scratch).
-#ifndef RT3_LDS_STACK
-#define RT3_LDS_STACK 20  // 20 KiB per 256-thread block -> 8 blocks = 8 waves per SIMD in 160 KiB (24 entries: 6 waves, 4 % slower; 16: more spills)
-#endif
-constexpr int kLdsStack = RT3_LDS_STACK;
+constexpr int kLdsStack = 20;  // 20 KiB per 256-thread block -> 8 blocks = 8 waves per SIMD in 160 KiB (24 entries: 6 waves, 4 % slower; 16: more spills)
 constexpr int kSpill = 64 - kLdsStack;  // kLdsStack + kSpill >= kMaxBvhDepth (checked on the host after the build)
 constexpr uint32_t kMaxSteps = 1u << 20;  // safety bound on traversal steps per ray (a corrupt tree must not hang the GPU)
 
