@@ -136,28 +136,35 @@ class PathTracer:
             torch.cuda.synchronize()
             self.ctx.check(lib.rt3_image_unpack_tiles(h, img, r, self.n_ranks, C.c_void_p(buf.data_ptr())))
 
+        # The untile kernels run asynchronously on librt3's stream, which torch's caching allocator knows nothing about: every
+        # buffer they read must stay alive until that stream has drained (`finish`), or the allocator hands the block to the
+        # next tensor while a kernel still reads it.
         if self.host_staged_gather:
+            staged = []
+
             def pack_host(buf):
                 g = torch.zeros_like(buf, device=dev)
                 pack(g)
                 buf.copy_(g.cpu())
 
             def unpack_host(r, buf):
-                unpack(r, buf.to(dev))
+                staged.append(buf.to(dev))
+                unpack(r, staged[-1])
 
-            done = gather_tiles(dist, torch, torch.device("cpu"), self.rank, self.n_ranks, counts, pack_host, unpack_host, dst)
+            done = gather_tiles(dist, torch, torch.device("cpu"), self.rank, self.n_ranks, counts, pack_host, unpack_host, dst, finish=self.ctx.wait)
+            staged.clear()
         else:
-            done = gather_tiles(dist, torch, dev, self.rank, self.n_ranks, counts, pack, unpack, dst)
+            done = gather_tiles(dist, torch, dev, self.rank, self.n_ranks, counts, pack, unpack, dst, finish=self.ctx.wait)
         if not done:
             return None
-        self.ctx.wait()
         return self.light() if download else True
 
 
-def gather_tiles(dist, torch, device, rank, n_ranks, counts, pack, unpack, dst=0):
+def gather_tiles(dist, torch, device, rank, n_ranks, counts, pack, unpack, dst=0, finish=None):
     """The one collective of a frame (north_star): every rank contributes its contiguous tile buffer
     (max(counts) x RGBA32F, zero padded) to ONE `dist.gather` on `dst`; `dst` hands each received buffer to `unpack`.
     `pack(buf)` fills this rank's buffer, `unpack(r, buf)` scatters rank r's pixels into the full image.
+    `finish()` (optional) is called on `dst` after the last `unpack`, while the received buffers are still alive.
     Backend-agnostic (nccl == RCCL on the GPUs, gloo in the CPU tests).  Returns True on `dst`."""
     cap = max(counts)
     mine = torch.zeros((cap, 4), dtype=torch.float32, device=device)
@@ -167,6 +174,8 @@ def gather_tiles(dist, torch, device, rank, n_ranks, counts, pack, unpack, dst=0
         dist.gather(mine, parts, dst=dst)
         for r, p in enumerate(parts):
             unpack(r, p)
+        if finish is not None:
+            finish()
         return True
     dist.gather(mine, None, dst=dst)
     return False

@@ -530,3 +530,24 @@ def test_fused_and_separate_traversal_launches_agree(small):
     assert sa.trace_launches == 0 and sb.trace_launches == 3 and sb.extend_launches == 1 and sb.shadow_launches == 1
     assert sb.trace_rays[0] == sb.extension_rays - W * H  # every bounce ray, not the primary rays of the gbuffer pass
     assert 0 < sb.trace_rays[1] < sb.shadow_rays and 0 < sb.trace_nodes[0] < sb.nodes_visited and 0 < sb.trace_nodes[1] < sb.shadow_nodes_visited
+
+
+def test_multi_rank_gather_rehearsal(tmp_path):
+    """bench.py --gpus 3 as the driver launches it (torch.distributed.run, one process per rank), in the rehearsal mode for a
+    1-GPU box (RT3_DIST_BACKEND=gloo: the ranks share GPU 0 and the one gather goes through host tensors): the frame
+    assembled on rank 0 from three ranks' tiles must be bit-identical to a single-rank render of it."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, RT3_DIST_BACKEND="gloo", RT3_CHECK_GATHER="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           str(root / "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "1", "--no-cpu", "--width", "328", "--height", "200", "--spp", "4", "--detail", "0.3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 3 and d["gather_bit_identical_to_single_rank"] is True and d["value"] > 0
