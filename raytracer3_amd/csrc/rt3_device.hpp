@@ -513,21 +513,40 @@ RT3_DEV uint32_t cdf_find_guided(const float* cdfp, const uint32_t* guide, uint3
     hi_v = cdfp[lo + 1];
     return lo;
 }
-RT3_DEV void sky_sample(const SceneDev& sc, float u0, float u1, V3& dir, V3& rad, float& pdf) {
+// Light sample in two steps, so that the caller can drop samples below the surface's horizon (cos <= 0: nearly half of
+// them) BEFORE paying for the radiance texels: (1) invert the CDFs -> texel, equirect coordinates, direction;
+// (2) bilinear radiance + the texel's density.
+struct SkyPick {
+    float u, v, sin_theta;
+    int x, y;
+};
+RT3_DEV SkyPick sky_sample_direction(const SceneDev& sc, float u0, float u1, V3& dir) {
     uint32_t W = sc.sky_w, H = sc.sky_h;
     float lo, hi;
     uint32_t y = cdf_find_guided(sc.cdf_marg, sc.guide_marg, H, u0, lo, hi);
     float dv = hi > lo ? (u0 - lo) / (hi - lo) : 0.5f;
     uint32_t x = cdf_find_guided(sc.cdf_cond + (size_t)y * (W + 4), sc.guide_cond + (size_t)y * W, W, u1, lo, hi);
     float du = hi > lo ? (u1 - lo) / (hi - lo) : 0.5f;
-    float u = ((float)x + du) / (float)W, v = ((float)y + dv) / (float)H;
+    SkyPick p;
+    p.u = ((float)x + du) / (float)W;
+    p.v = ((float)y + dv) / (float)H;
+    p.x = (int)x;
+    p.y = (int)y;
     float st, ct, s2, c2;
-    sincos_2pi(v * 0.5f, st, ct);
-    sincos_2pi(u, s2, c2);
+    sincos_2pi(p.v * 0.5f, st, ct);
+    sincos_2pi(p.u, s2, c2);
+    p.sin_theta = st;
     dir = v3((-c2) * st, ct, (-s2) * st);
+    return p;
+}
+RT3_DEV void sky_sample_radiance(const SceneDev& sc, const SkyPick& p, V3& rad, float& pdf) {
     float pt;
-    rad = sky_eval_pdf(sc, u, v, (int)x, (int)y, pt);
-    pdf = st > 0.0f ? pt / (2.0f * kPi * kPi * st) : 0.0f;
+    rad = sky_eval_pdf(sc, p.u, p.v, p.x, p.y, pt);
+    pdf = p.sin_theta > 0.0f ? pt / (2.0f * kPi * kPi * p.sin_theta) : 0.0f;
+}
+RT3_DEV void sky_sample(const SceneDev& sc, float u0, float u1, V3& dir, V3& rad, float& pdf) {
+    const SkyPick p = sky_sample_direction(sc, u0, u1, dir);
+    sky_sample_radiance(sc, p, rad, pdf);
 }
 
 // ------------------------------------------------------------------------------------------------ intersection (north_star)

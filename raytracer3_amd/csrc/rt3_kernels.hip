@@ -625,20 +625,23 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
                 u0 = bluenoise_shift(u0, bn & 0xFFu);
                 u1 = bluenoise_shift(u1, (bn >> 8) & 0xFFu);
             }
+            V3 N = surf.normal;
+            if ((flags & RT3_FLAG_FACEFORWARD) && dot(N, d) > 0.0f) N = neg(N);
             // the light sample first: its chain of dependent table gathers (guide -> CDF -> guide -> CDF -> texels) is then in
-            // flight while the BSDF is set up and sampled below
+            // flight while the BSDF is set up and sampled below.  Samples below the horizon of the surface (cos <= 0) are
+            // dropped before the radiance texels are fetched: those two cache lines are the expensive part of a light sample.
             V3 rad = v3(0.0f, 0.0f, 0.0f);
-            float pl = 0.0f;
+            float pl = 0.0f, cosl = 0.0f;
             if (nee) {
                 float ul0 = uniform_float(seed, base + 3), ul1 = uniform_float(seed, base + 4);
                 if (bnz) {
                     ul0 = bluenoise_shift(ul0, (bn >> 16) & 0xFFu);
                     ul1 = bluenoise_shift(ul1, (bn >> 24) & 0xFFu);
                 }
-                sky_sample(a.sc, ul0, ul1, wl, rad, pl);
+                const SkyPick pick = sky_sample_direction(a.sc, ul0, ul1, wl);
+                cosl = dot(N, wl);
+                if (cosl > 0.0f) sky_sample_radiance(a.sc, pick, rad, pl);
             }
-            V3 N = surf.normal;
-            if ((flags & RT3_FLAG_FACEFORWARD) && dot(N, d) > 0.0f) N = neg(N);
             V3 b1, b2;
             build_orthonormal_basis(N, b1, b2);  // :44
             V3 wi, vop = surf.albedo, wo = v3(0.0f, 0.0f, 1.0f);
@@ -664,7 +667,6 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
                 *Lp = make_float4(lv.x + T.x * surf.emissive.x, lv.y + T.y * surf.emissive.y, lv.z + T.z * surf.emissive.z, 0.0f);
             }
             if (nee) {
-                float cosl = dot(N, wl);
                 if (cosl > 0.0f && pl > 0.0f) {
                     V3 fv;
                     float scale;
