@@ -644,16 +644,19 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
             }
             V3 b1, b2;
             build_orthonormal_basis(N, b1, b2);  // :44
-            V3 wi, vop = surf.albedo, wo = v3(0.0f, 0.0f, 1.0f);
-            float pdf_s;
+            V3 wi = v3(0.0f, 0.0f, 1.0f), vop = surf.albedo, wo = v3(0.0f, 0.0f, 1.0f);
+            float pdf_s = 0.0f;
             bool valid = true;
             Bsdf bs;
+            const bool last = b == B - 1;  // the last vertex of a path emits no extension ray (:53): its BSDF sample is never used
             if (spec) {  // layered diffuse + GGX (brdf.slang:141-311)
                 bs = bsdf_setup(surf.albedo, surf.roughness, surf.metalness);
                 wo = v3(-(d.x * b1.x + d.y * b1.y + d.z * b1.z), -(d.x * b2.x + d.y * b2.y + d.z * b2.z), -(d.x * N.x + d.y * N.y + d.z * N.z));
-                float u2 = uniform_float(seed, base + 2);
-                valid = bsdf_sample(bs, wo, u0, u1, u2, wi, vop, pdf_s);
-            } else {
+                if (!last) {
+                    float u2 = uniform_float(seed, base + 2);
+                    valid = bsdf_sample(bs, wo, u0, u1, u2, wi, vop, pdf_s);
+                }
+            } else if (!last) {
                 wi = diffuse_sample(u0, u1);  // :45
                 pdf_s = wi.z * kInvPi;
             }
@@ -684,11 +687,11 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
                     emit_shadow = true;
                 }
             }
-            if (valid) {  // an invalid specular sample (brdf.slang:227-229) ends the path
+            if (valid && !last) {  // an invalid specular sample (brdf.slang:227-229) ends the path
                 nd = basis_apply(b1, b2, N, wi);  // :48
                 pdf_n = pdf_s;
                 Tn = T * vop;                     // :51 value_over_pdf (= albedo for the diffuse BRDF)
-                emit_ext = b != B - 1;            // :53
+                emit_ext = true;                  // :53
             }
         }
         const BlockAppend slot = block_append2(emit_ext, a.out_count, emit_shadow, a.sh_count, append_lds[parity]);
