@@ -418,9 +418,18 @@ RT3_DEV V3 texture_sample(const SceneDev& sc, uint32_t index, float u, float v) 
     }
     return v3(o[0], o[1], o[2]);
 }
-RT3_DEV Surface hit_info(const SceneDev& sc, uint32_t prim, float bu, float bv) {
+// In two steps so that a caller can put independent work (the light sample's table gathers) between the issue of the
+// 64-byte shading-record loads and their use.
+struct HitRecord {
+    float4 a, b, c;
+    const float4* rec;
+};
+RT3_DEV HitRecord hit_fetch(const SceneDev& sc, uint32_t prim) {
     const float4* rec = sc.tri_shade + 4 * (size_t)prim;
-    float4 a = rec[0], b = rec[1], c = rec[2];
+    return HitRecord{rec[0], rec[1], rec[2], rec};
+}
+RT3_DEV Surface hit_finish(const SceneDev& sc, const HitRecord& h, float bu, float bv) {
+    const float4 a = h.a, b = h.b, c = h.c;
     const GeometryInfoDev& gi = sc.geoms[__float_as_uint(c.y)];
     float b0 = 1.0f - bu - bv;
     V3 n = v3(a.x * b0 + a.w * bu + b.z * bv, a.y * b0 + b.x * bu + b.w * bv, a.z * b0 + b.y * bu + c.x * bv);
@@ -428,7 +437,7 @@ RT3_DEV Surface hit_info(const SceneDev& sc, uint32_t prim, float bu, float bv) 
     Surface s;
     s.albedo = v3(gi.base_color[0], gi.base_color[1], gi.base_color[2]);
     if (gi.tex > -1 && (uint32_t)gi.tex < sc.n_tex) {  // :27,31-33
-        float4 e = rec[3];
+        float4 e = h.rec[3];
         float uu = c.z * b0 + e.x * bu + e.z * bv, vv = c.w * b0 + e.y * bu + e.w * bv;
         s.albedo = s.albedo * texture_sample(sc, (uint32_t)gi.tex, uu, vv);
     }
@@ -438,6 +447,7 @@ RT3_DEV Surface hit_info(const SceneDev& sc, uint32_t prim, float bu, float bv) 
     s.metalness = gi.metallic;
     return s;
 }
+RT3_DEV Surface hit_info(const SceneDev& sc, uint32_t prim, float bu, float bv) { return hit_finish(sc, hit_fetch(sc, prim), bu, bv); }
 
 // ------------------------------------------------------------------------------------------------ sky (north_star)
 // Texels are stored as float4 {r, g, b, pdf_uv}: the importance-sampling density of a texel travels with its colour, so

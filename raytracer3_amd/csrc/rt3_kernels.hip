@@ -564,6 +564,10 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
         surf.roughness = 1.0f;
         surf.metalness = 0.0f;
         uint32_t px = 0, py = 0, sample_in_batch = 0;
+        HitRecord hrecord;
+        hrecord.a = hrecord.b = hrecord.c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        hrecord.rec = a.sc.tri_shade;
+        float hbu = 0.0f, hbv = 0.0f;
         if (active) {
             pid = FIRST ? i : a.in_pid[i];
             sample_in_batch = fast_div(a.npix_div, pid);
@@ -607,7 +611,9 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
                 active = false;
             } else {
                 t = hrec.x;
-                surf = hit_info(a.sc, prim, hrec.y, hrec.z);  // :55
+                hbu = hrec.y;
+                hbv = hrec.z;
+                hrecord = hit_fetch(a.sc, prim);  // :55, first half: the loads are issued here, used after the light-sample gathers
             }
         }
         bool emit_shadow = false, emit_ext = false;
@@ -625,20 +631,27 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
                 u0 = bluenoise_shift(u0, bn & 0xFFu);
                 u1 = bluenoise_shift(u1, (bn >> 8) & 0xFFu);
             }
-            V3 N = surf.normal;
-            if ((flags & RT3_FLAG_FACEFORWARD) && dot(N, d) > 0.0f) N = neg(N);
             // the light sample first: its chain of dependent table gathers (guide -> CDF -> guide -> CDF -> texels) is then in
-            // flight while the BSDF is set up and sampled below.  Samples below the horizon of the surface (cos <= 0) are
-            // dropped before the radiance texels are fetched: those two cache lines are the expensive part of a light sample.
+            // flight while the shading record arrives and the BSDF is set up and sampled below.  Samples below the horizon
+            // of the surface (cos <= 0) are dropped before the radiance texels are fetched: those two cache lines are the
+            // expensive part of a light sample.
             V3 rad = v3(0.0f, 0.0f, 0.0f);
             float pl = 0.0f, cosl = 0.0f;
+            SkyPick pick;
+            pick.u = pick.v = pick.sin_theta = 0.0f;
+            pick.x = pick.y = 0;
             if (nee) {
                 float ul0 = uniform_float(seed, base + 3), ul1 = uniform_float(seed, base + 4);
                 if (bnz) {
                     ul0 = bluenoise_shift(ul0, (bn >> 16) & 0xFFu);
                     ul1 = bluenoise_shift(ul1, (bn >> 24) & 0xFFu);
                 }
-                const SkyPick pick = sky_sample_direction(a.sc, ul0, ul1, wl);
+                pick = sky_sample_direction(a.sc, ul0, ul1, wl);
+            }
+            if (!FIRST) surf = hit_finish(a.sc, hrecord, hbu, hbv);  // :55, second half
+            V3 N = surf.normal;
+            if ((flags & RT3_FLAG_FACEFORWARD) && dot(N, d) > 0.0f) N = neg(N);
+            if (nee) {
                 cosl = dot(N, wl);
                 if (cosl > 0.0f) sky_sample_radiance(a.sc, pick, rad, pl);
             }
