@@ -453,9 +453,11 @@ int pass_reference_mode(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y,
                 launch_shade(c->stream, bn == 0, L);
             }
             cur ^= 1;
-            // both queues in one launch: one machine-wide drain less per bounce.  It pays when launches are short (a frame split over
-            // 8 GPUs: -1.7 %) and costs 2 % on the single-GPU frame, where each launch runs for > 10 ms: decided by the batch size
-            const bool fuse = c->opt_fused_trace == 1 || (c->opt_fused_trace < 0 && n_first <= (24u << 20));
+            // both queues in one launch (k_trace): a launch of the persistent walk ends in a drain -- the waves finish spread over the
+            // time their longest last ray takes (~0.15 ms, measured with per-wave clocks, whatever the chunk size) -- and one launch
+            // per bounce has one drain less than two.  That is +3 % when the frame is split over 8 GPUs (launches of ~2 ms),
+            // +2 % over 4, and nothing on the single-GPU frame (launches > 10 ms), which keeps the separate kernels.
+            const bool fuse = c->opt_fused_trace == 1 || (c->opt_fused_trace < 0 && n_first <= (96u << 20));
             if (nee && bn != B - 1 && fuse) {
                 ScopedTimer t(c, CAT_TRACE);
                 launch_trace(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->rays[cur], c->sh_rays, S, ext_cnt + bn, sh_cnt + bn, n_first,

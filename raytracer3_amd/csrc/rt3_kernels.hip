@@ -85,10 +85,19 @@ struct LaneRay {  // traversal state of the ray a lane currently owns
     int sp;
 };
 
-template <bool ANY, bool COUNT, int LAYOUT, typename Finish>
+// MODE 0: closest hit over one queue; 1: any hit over one queue; 2: both queues in one walk -- the lanes of a wave take
+// extension rays (closest hit) until that pool is dry and shadow rays (any hit) from then on, so the two kinds share a
+// wave for a while and no lane waits for the wave's last extension ray before it starts on shadow rays.
+template <int MODE, bool COUNT, int LAYOUT, typename Finish>
 __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, const float4* __restrict__ tris,
-                                             const float* __restrict__ rays, size_t stride, uint32_t n, uint32_t* __restrict__ work_counter,
-                                             uint32_t* __restrict__ lds, Finish finish) {
+                                             const float* __restrict__ rays_a, size_t stride, uint32_t n_a, uint32_t* __restrict__ work_counter_a,
+                                             uint32_t* __restrict__ lds, Finish finish, const float* __restrict__ rays_b = nullptr, uint32_t n_b = 0,
+                                             uint32_t* __restrict__ work_counter_b = nullptr) {
+    const float* __restrict__ rays = rays_a;
+    uint32_t n = n_a;
+    uint32_t* __restrict__ work_counter = work_counter_a;
+    bool second_pool = false;  // MODE 2: wave-uniform, true once this wave has moved on to the shadow queue
+    bool lane_any = MODE == 1;
     constexpr bool WIDE = LAYOUT == kLayoutWide128;   // 8 x 16 B per fetch
     constexpr bool WIDEQ = LAYOUT == kLayoutWide64Q || LAYOUT == kLayoutWide48Q;  // quantised boxes
     constexpr bool C48 = LAYOUT == kLayoutWide48Q;  // 3 x 16 B per fetch: node and triangle records are both 48 B
@@ -131,6 +140,16 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
             queue_empty = base >= n;
             pool_next = base < n ? base : n;
             pool_end = (n - pool_next) > kPoolChunk ? pool_next + kPoolChunk : n;
+            if (MODE == 2 && queue_empty && !second_pool) {  // extension queue dry: this wave's idle lanes go on with shadow rays
+                second_pool = true;
+                rays = rays_b;
+                n = n_b;
+                work_counter = work_counter_b;
+                first_chunk = true;
+                queue_empty = false;
+                pool_next = pool_end = 0;
+                continue;
+            }
         }
         if (m_idle != 0ull && pool_next < pool_end && ((uint32_t)__popcll(m_idle) >= kRefillLanes || m_idle == ~0ull)) {
             const uint32_t idx = pool_next + (uint32_t)__popcll(m_idle & lanes_below);
@@ -148,8 +167,9 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
                 r.steps = 0u;
                 r.cn = r.ct = 0u;
                 busy = true;
+                if (MODE == 2) lane_any = second_pool;
                 if (nodes == nullptr) {  // empty scene: everything misses
-                    finish(r.index, r.best, 0u, 0u);
+                    finish(r.index, r.best, 0u, 0u, MODE == 2 ? lane_any : MODE == 1);
                     busy = false;
                 }
             }
@@ -162,6 +182,7 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
         }
         if (!busy) continue;
         // ---- one traversal step
+        const bool ANY = MODE == 2 ? lane_any : MODE == 1;  // compile-time constant for MODE 0 / 1, per lane for MODE 2
         const bool is_leaf = (r.cur & 0x80000000u) != 0u;
         const uint32_t first = r.cur & 0x0FFFFFFFu, cnt = ((r.cur >> 28) & 7u) + 1u;
         const float4* p = is_leaf ? tris + 3 * (size_t)(first + r.leaf_k) : nodes + (WIDE ? 8 : (C48 ? kC48Stride : 4)) * (size_t)r.cur;
@@ -320,7 +341,7 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
         // kMaxSteps bounds the walk so that a corrupt tree can never hang the GPU (a valid tree visits < 2 n nodes)
         if (++r.steps >= kMaxSteps) done = true;
         if (done) {
-            finish(r.index, r.best, r.cn, r.ct);
+            finish(r.index, r.best, r.cn, r.ct, MODE == 2 ? lane_any : MODE == 1);
             busy = false;
         }
     }
@@ -338,7 +359,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(const float4* __restric
     __shared__ uint32_t stack[kLdsStack * kExtendBlock];
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
     unsigned long long tot_n = 0, tot_t = 0;
-    trace_stream<false, COUNT, LAYOUT>(nodes, tris, rays, stride, n, work_counter, stack + threadIdx.x, [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct) {
+    trace_stream<0, COUNT, LAYOUT>(nodes, tris, rays, stride, n, work_counter, stack + threadIdx.x, [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, bool) {
         // one 16-byte record per ray: with persistent waves rays finish out of order, four SoA streams would be four
         // scattered partial-line writes
         reinterpret_cast<float4*>(hits)[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
@@ -369,7 +390,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_shadow(const float4* __restric
     __shared__ uint32_t stack[kLdsStack * kExtendBlock];
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
     unsigned long long tot_n = 0, tot_t = 0;
-    trace_stream<true, COUNT, LAYOUT>(nodes, tris, rays, stride, n, work_counter, stack + threadIdx.x, [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct) {
+    trace_stream<1, COUNT, LAYOUT>(nodes, tris, rays, stride, n, work_counter, stack + threadIdx.x, [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, bool) {
         if (occluded_out) {
             occluded_out[i] = h.prim != kMiss ? 1u : 0u;
         } else if (h.prim == kMiss) {
@@ -392,8 +413,8 @@ __global__ __launch_bounds__(kExtendBlock) void k_shadow(const float4* __restric
     }
 }
 
-// One launch per bounce for BOTH ray kinds: every wave first helps to drain the extension queue (closest hit), then the
-// shadow queue (any hit), without a grid-wide barrier in between -- a launch boundary idles the machine while the last
+// One launch per bounce for BOTH ray kinds: the lanes of every wave take extension rays (closest hit) until that queue is dry and
+// shadow rays (any hit) from then on -- no grid-wide barrier and no per-wave drain in between -- a launch boundary idles the machine while the last
 // waves finish (each k_extend / k_shadow pair cost one such drain more), which matters most when the frame is split
 // over several GPUs and every launch is 1/N as long.  totals (counting mode): {rays, nodes, tris} x {closest, any}.
 template <bool COUNT, int LAYOUT>
@@ -406,25 +427,25 @@ __global__ __launch_bounds__(kExtendBlock) void k_trace(const float4* __restrict
     __shared__ uint32_t stack[kLdsStack * kExtendBlock];
     const uint32_t n_ext = *ext_count, n_sh = *sh_count;
     unsigned long long en = 0, et = 0, sn = 0, stt = 0;
-    trace_stream<false, COUNT, LAYOUT>(nodes, tris, ext_rays, stride, n_ext, work_ext, stack + threadIdx.x, [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct) {
-        reinterpret_cast<float4*>(hits)[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
-        if (COUNT) {
-            en += cn;
-            et += ct;
-        }
-    });
-    trace_stream<true, COUNT, LAYOUT>(nodes, tris, sh_rays, stride, n_sh, work_sh, stack + threadIdx.x, [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct) {
-        if (h.prim == kMiss) {
-            const float4 c = reinterpret_cast<const float4*>(contrib)[i];  // {rgb, path id}
-            float4* L = reinterpret_cast<float4*>(lacc) + __float_as_uint(c.w);
-            float4 v = *L;
-            *L = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, 0.0f);
-        }
-        if (COUNT) {
-            sn += cn;
-            stt += ct;
-        }
-    });
+    trace_stream<2, COUNT, LAYOUT>(
+        nodes, tris, ext_rays, stride, n_ext, work_ext, stack + threadIdx.x,
+        [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, bool any) {
+            if (!any) {
+                reinterpret_cast<float4*>(hits)[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
+            } else if (h.prim == kMiss) {
+                const float4 c = reinterpret_cast<const float4*>(contrib)[i];  // {rgb, path id}
+                float4* L = reinterpret_cast<float4*>(lacc) + __float_as_uint(c.w);
+                float4 v = *L;
+                *L = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, 0.0f);
+            }
+            if (COUNT) {
+                en += any ? 0u : cn;
+                et += any ? 0u : ct;
+                sn += any ? cn : 0u;
+                stt += any ? ct : 0u;
+            }
+        },
+        sh_rays, n_sh, work_sh);
     if (COUNT && totals) {
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             atomicAdd(&totals[0], (unsigned long long)n_ext);
