@@ -530,10 +530,11 @@ struct SkyPick {
     float u, v, sin_theta;
     int x, y;
 };
-RT3_DEV SkyPick sky_sample_direction(const SceneDev& sc, float u0, float u1, V3& dir) {
+// cdf_marg / guide_marg: the marginal tables (the caller may have staged them in LDS)
+RT3_DEV SkyPick sky_sample_direction(const SceneDev& sc, const float* cdf_marg, const uint32_t* guide_marg, float u0, float u1, V3& dir) {
     uint32_t W = sc.sky_w, H = sc.sky_h;
     float lo, hi;
-    uint32_t y = cdf_find_guided(sc.cdf_marg, sc.guide_marg, H, u0, lo, hi);
+    uint32_t y = cdf_find_guided(cdf_marg, guide_marg, H, u0, lo, hi);
     float dv = hi > lo ? (u0 - lo) / (hi - lo) : 0.5f;
     uint32_t x = cdf_find_guided(sc.cdf_cond + (size_t)y * (W + 4), sc.guide_cond + (size_t)y * W, W, u1, lo, hi);
     float du = hi > lo ? (u1 - lo) / (hi - lo) : 0.5f;
@@ -555,7 +556,7 @@ RT3_DEV void sky_sample_radiance(const SceneDev& sc, const SkyPick& p, V3& rad, 
     pdf = p.sin_theta > 0.0f ? pt / (2.0f * kPi * kPi * p.sin_theta) : 0.0f;
 }
 RT3_DEV void sky_sample(const SceneDev& sc, float u0, float u1, V3& dir, V3& rad, float& pdf) {
-    const SkyPick p = sky_sample_direction(sc, u0, u1, dir);
+    const SkyPick p = sky_sample_direction(sc, sc.cdf_marg, sc.guide_marg, u0, u1, dir);
     sky_sample_radiance(sc, p, rad, pdf);
 }
 

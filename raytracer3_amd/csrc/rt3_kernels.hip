@@ -565,6 +565,19 @@ template <bool FIRST>
 __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
     __shared__ uint32_t append_lds[2][2 * (kShadeBlock / 64 + 1)];  // double-buffered: see block_append2
     uint32_t parity = 0;
+    // the marginal sky tables (one guide word + one CDF value per row) are the first two links of every light sample's chain of
+    // dependent lookups: staged in LDS they cost ~100 cycles each instead of an L1/L2 round trip
+    constexpr uint32_t kMargRows = 2048;
+    __shared__ uint32_t s_guide_marg[kMargRows];
+    __shared__ float s_cdf_marg[kMargRows + 4];
+    const bool marg_in_lds = (a.g.pad[0] & RT3_FLAG_NEE_SKY) && a.sc.sky != nullptr && a.sc.sky_h <= kMargRows;
+    if (marg_in_lds) {
+        for (uint32_t k = threadIdx.x; k < a.sc.sky_h; k += kShadeBlock) s_guide_marg[k] = a.sc.guide_marg[k];
+        for (uint32_t k = threadIdx.x; k < a.sc.sky_h + 4u; k += kShadeBlock) s_cdf_marg[k] = a.sc.cdf_marg[k];
+        __syncthreads();
+    }
+    const float* cdf_marg = marg_in_lds ? s_cdf_marg : a.sc.cdf_marg;
+    const uint32_t* guide_marg = marg_in_lds ? s_guide_marg : a.sc.guide_marg;
     const GConstDev& g = a.g;
     const uint32_t flags = g.pad[0], B = g.bounces, b = a.bounce;
     const uint32_t dims = flags ? 8u : 2u;
@@ -667,7 +680,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
                     ul0 = bluenoise_shift(ul0, (bn >> 16) & 0xFFu);
                     ul1 = bluenoise_shift(ul1, (bn >> 24) & 0xFFu);
                 }
-                pick = sky_sample_direction(a.sc, ul0, ul1, wl);
+                pick = sky_sample_direction(a.sc, cdf_marg, guide_marg, ul0, ul1, wl);
             }
             if (!FIRST) surf = hit_finish(a.sc, hrecord, hbu, hbv);  // :55, second half
             V3 N = surf.normal;
