@@ -35,6 +35,8 @@ struct Resource {
 struct PixelList {
     uint32_t w, h, rank, n_ranks, count;
     uint32_t* dev;
+    uint2* dev_bn = nullptr;      // {x | y << 16, blue-noise word of that pixel}: one load instead of two dependent ones in k_shade
+    uint64_t bn_stamp = ~0ull;    // which blue-noise upload dev_bn was built from
 };
 enum Cat { CAT_EXTEND = 0, CAT_SHADOW = 1, CAT_SHADE = 2, CAT_OTHER = 3, CAT_TRACE = 4 };
 struct Timed {
@@ -65,6 +67,7 @@ struct rt3_ctx {
     uint32_t sky_w = 0, sky_h = 0;
     uint8_t* d_bn = nullptr;
     uint32_t bn_w = 0, bn_h = 0;
+    uint64_t bn_stamp = 0;  // bumped by every rt3_scene_set_bluenoise
     // base-colour textures: host staging (RGBA8) + device atlas rebuilt lazily
     std::vector<std::vector<uint8_t>> h_tex;
     std::vector<uint32_t> tex_w, tex_h;
@@ -163,7 +166,8 @@ int get_pixlist(rt3_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_t n_ra
     if (w == 0 || h == 0 || w > 65535 || h > 65535 || n_ranks == 0 || rank >= n_ranks) return fail(c, RT3_E_INVALID, "bad window / rank for tile partition");
     std::vector<uint32_t> px;
     tile_pixels(w, h, rank, n_ranks, px);
-    PixelList pl{w, h, rank, n_ranks, (uint32_t)px.size(), nullptr};
+    PixelList pl;
+    pl.w = w; pl.h = h; pl.rank = rank; pl.n_ranks = n_ranks; pl.count = (uint32_t)px.size(); pl.dev = nullptr;
     HIPC(c, hipMalloc((void**)&pl.dev, (px.size() ? px.size() : 1) * 4));
     if (!px.empty()) HIPC(c, hipMemcpy(pl.dev, px.data(), px.size() * 4, hipMemcpyHostToDevice));
     c->pixlists.push_back(pl);
@@ -205,8 +209,6 @@ SceneDev scene_dev(const rt3_ctx* c) {
     s.bluenoise = c->d_bn;
     s.bn_w = c->bn_w;
     s.bn_h = c->bn_h;
-    s.bn_w_div = make_fastdiv(c->bn_w);
-    s.bn_h_div = make_fastdiv(c->bn_h);
     s.tex_pixels = c->d_tex_pixels;
     s.tex_table = c->d_tex_table;
     s.srgb_lut = c->d_srgb_lut;
@@ -417,6 +419,11 @@ int pass_reference_mode(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y,
     if (int r = get_pixlist(c, W, H, c->rank, c->n_ranks, &pl)) return r;
     const uint32_t npix = pl->count;
     if (npix == 0) return RT3_OK;
+    if (pl->bn_stamp != c->bn_stamp || !pl->dev_bn) {  // (re)build the {pixel, blue-noise word} list of this window / rank
+        if (!pl->dev_bn) HIPC(c, hipMalloc((void**)&pl->dev_bn, (size_t)npix * 8));
+        launch_pixbn(c->stream, pl->dev, npix, c->d_bn, c->bn_w, c->bn_h, pl->dev_bn);
+        pl->bn_stamp = c->bn_stamp;
+    }
     // paths per wavefront batch: 188 B of queue state each, so 2^28 paths = 50 GB of the 288 GB; the C3 frame (132.7 M paths)
     // is ONE batch.  Larger launches amortise the ramp / tail of the persistent traversal kernels: 16 -> 64 spp per batch = -6.5 % frame time.
     uint64_t max_paths = 1ull << 28;
@@ -441,7 +448,7 @@ int pass_reference_mode(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y,
         int cur = 0;
         for (uint32_t bn = 0; bn < B; bn++) {
             ShadeLaunch L;
-            L.g = gd; L.sc = sc; L.pixels = pl->dev; L.npix = npix; L.width = W; L.s0 = s0; L.bounce = bn;
+            L.g = gd; L.sc = sc; L.pixels = pl->dev; L.pixbn = pl->dev_bn; L.npix = npix; L.width = W; L.s0 = s0; L.bounce = bn;
             L.gbuffer = gb->ptr; L.depth = (const float*)dp->ptr;
             L.in_rays = c->rays[cur]; L.in_hits = c->hits; L.in_T = c->T[cur]; L.in_pid = c->pid[cur];
             L.in_count = bn ? ext_cnt + (bn - 1) : nullptr; L.n_first = n_first;
@@ -545,7 +552,10 @@ void rt3_destroy(rt3_ctx* c) {
     dev_free(c->bvh.nodes); dev_free(c->bvh.tris); dev_free(c->bvh.tri_shade); dev_free(c->d_guide_cond); dev_free(c->d_guide_marg);
     for (auto& r : c->resources)
         if (r.owned && r.ptr) (void)hipFree(r.ptr);
-    for (auto& p : c->pixlists) (void)hipFree(p.dev);
+    for (auto& p : c->pixlists) {
+        (void)hipFree(p.dev);
+        (void)hipFree(p.dev_bn);
+    }
     for (int k = 0; k < 2; k++) { dev_free(c->rays[k]); dev_free(c->T[k]); dev_free(c->pid[k]); }
     dev_free(c->hits); dev_free(c->sh_rays); dev_free(c->sh_contrib); dev_free(c->sh_pid); dev_free(c->lacc); dev_free(c->radsum);
     dev_free(c->d_counters); dev_free(c->d_totals);
@@ -761,6 +771,7 @@ int rt3_scene_set_bluenoise(rt3_ctx* c, const uint8_t* rgba, uint32_t w, uint32_
     HIPC(c, hipMemcpy(c->d_bn, rgba, (size_t)w * h * 4, hipMemcpyHostToDevice));
     c->bn_w = w;
     c->bn_h = h;
+    c->bn_stamp++;
     return RT3_OK;
 }
 // base-colour texture `index` (RGBA8, sRGB-encoded colour), sampled by hit_info when GeometryInfo.baseColorTextureIndex == index

@@ -390,7 +390,6 @@ struct SceneDev {
     uint32_t sky_w, sky_h;
     const uint8_t* bluenoise;
     uint32_t bn_w, bn_h;
-    FastDiv bn_w_div, bn_h_div;
 };
 
 // hit_logic.slang:5-40 (transform = identity, vertex colour = 1).  The three index + three vertex gathers of

@@ -27,6 +27,7 @@ struct ShadeLaunch {
     GConstDev g;
     SceneDev sc;
     const uint32_t* pixels;
+    const uint2* pixbn;
     uint32_t npix, width, s0, bounce;
     const void* gbuffer;
     const float* depth;
@@ -62,6 +63,7 @@ void launch_trace(hipStream_t st, bool count, int layout, const float4* nodes, c
 void launch_gbuffer(hipStream_t st, const SceneDev& sc, const uint32_t* pixels, uint32_t npix, uint32_t width, const float* hits,
                     size_t stride, void* gbuffer, float* depth);
 void launch_shade(hipStream_t st, bool first, const ShadeLaunch& L);
+void launch_pixbn(hipStream_t st, const uint32_t* pixels, uint32_t npix, const uint8_t* bluenoise, uint32_t bn_w, uint32_t bn_h, uint2* out);
 void launch_accumulate(hipStream_t st, const GConstDev& g, const uint32_t* pixels, uint32_t npix, uint32_t width, const float* depth,
                        const float* lacc, size_t stride, uint32_t sb, int first_batch, int last_batch, float* radsum, void* light,
                        const void* prev);

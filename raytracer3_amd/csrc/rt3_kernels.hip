@@ -533,6 +533,7 @@ struct ShadeArgs {
     GConstDev g;
     SceneDev sc;
     const uint32_t* pixels;  // x | y << 16, this rank's pixels in render order
+    const uint2* pixbn;      // the same list with each pixel's blue-noise word beside it
     uint32_t npix, width;
     FastDiv npix_div;        // path id = sample_in_batch * npix + pixel_index
     uint32_t s0;             // first sample index of this batch
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
         surf.normal = v3(0, 0, 1);
         surf.roughness = 1.0f;
         surf.metalness = 0.0f;
-        uint32_t px = 0, py = 0, sample_in_batch = 0;
+        uint32_t px = 0, py = 0, sample_in_batch = 0, bn = 0;
         HitRecord hrecord;
         hrecord.a = hrecord.b = hrecord.c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         hrecord.rec = a.sc.tri_shade;
@@ -605,9 +606,10 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
         if (active) {
             pid = FIRST ? i : a.in_pid[i];
             sample_in_batch = fast_div(a.npix_div, pid);
-            uint32_t xy = a.pixels[pid - sample_in_batch * a.npix];
-            px = xy & 0xFFFFu;
-            py = xy >> 16;
+            const uint2 pb = a.pixbn[pid - sample_in_batch * a.npix];  // pixel and its blue-noise word in one load
+            px = pb.x & 0xFFFFu;
+            py = pb.x >> 16;
+            bn = pb.y;
         }
         if (FIRST) {
             if (active) {
@@ -658,10 +660,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
             uint32_t sm = a.s0 + sample_in_batch;
             uint32_t base = (sm * B + b) * dims;
             float u0 = uniform_float(seed, base), u1 = uniform_float(seed, base + 1);  // :43
-            uint32_t bn = 0;
-            if (bnz) {
-                const uint32_t by = py - fast_div(a.sc.bn_h_div, py) * a.sc.bn_h, bx = px - fast_div(a.sc.bn_w_div, px) * a.sc.bn_w;  // py % bn_h, px % bn_w
-                bn = *reinterpret_cast<const uint32_t*>(a.sc.bluenoise + 4 * ((size_t)by * a.sc.bn_w + bx));
+            if (bnz) {  // bn = bluenoise[(py % bn_h), (px % bn_w)], gathered once per pixel list (k_pixbn)
                 u0 = bluenoise_shift(u0, bn & 0xFFu);
                 u1 = bluenoise_shift(u1, (bn >> 8) & 0xFFu);
             }
@@ -1018,10 +1017,23 @@ void launch_gbuffer(hipStream_t st, const SceneDev& sc, const uint32_t* pixels, 
                     size_t stride, void* gbuffer, float* depth) {
     hipLaunchKernelGGL(k_gbuffer, dim3(grid_for(npix, 256, 4096)), dim3(256), 0, st, sc, pixels, npix, width, hits, stride, (uint4*)gbuffer, depth);
 }
+__global__ void k_pixbn(const uint32_t* __restrict__ pixels, uint32_t npix, const uint8_t* __restrict__ bluenoise, uint32_t bn_w, uint32_t bn_h,
+                        uint2* __restrict__ out) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        const uint32_t xy = pixels[i], px = xy & 0xFFFFu, py = xy >> 16;
+        uint32_t bn = 0;
+        if (bluenoise) bn = *reinterpret_cast<const uint32_t*>(bluenoise + 4 * ((size_t)(py % bn_h) * bn_w + (px % bn_w)));
+        out[i] = make_uint2(xy, bn);
+    }
+}
+void launch_pixbn(hipStream_t st, const uint32_t* pixels, uint32_t npix, const uint8_t* bluenoise, uint32_t bn_w, uint32_t bn_h, uint2* out) {
+    hipLaunchKernelGGL(k_pixbn, dim3(grid_for(npix, 256, 4096)), dim3(256), 0, st, pixels, npix, bluenoise, bn_w, bn_h, out);
+}
 void launch_shade(hipStream_t st, bool first, const ShadeLaunch& L) {
     ShadeArgs a;
     a.g = L.g; a.sc = L.sc; a.pixels = L.pixels; a.npix = L.npix; a.width = L.width; a.s0 = L.s0; a.bounce = L.bounce;
     a.npix_div = make_fastdiv(L.npix);
+    a.pixbn = L.pixbn;
     a.gbuffer = (const uint4*)L.gbuffer; a.depth = L.depth;
     a.in_rays = L.in_rays; a.in_hits = L.in_hits; a.in_T = L.in_T; a.in_pid = L.in_pid; a.in_count = L.in_count; a.n_first = L.n_first;
     a.out_rays = L.out_rays; a.out_T = L.out_T; a.out_pid = L.out_pid; a.out_count = L.out_count;
