@@ -43,8 +43,8 @@ struct Timed {
     hipEvent_t a, b;
     int cat;
 };
-struct CounterBlock {  // device counters of one refrence_mode / gbuffer launch, harvested lazily
-    uint32_t first, n_ext, n_sh;  // slots [first, first+n_ext) are extension-queue sizes, then n_sh shadow-queue sizes
+struct CounterBlock {  // device counters of one refrence_mode launch, harvested lazily
+    uint32_t first, n_pairs;  // n_pairs x {extension-queue size, shadow-queue size}: one 8-byte pair per bounce (k_shade bumps both with ONE 64-bit atomic)
 };
 
 }  // namespace
@@ -273,8 +273,10 @@ int harvest(rt3_ctx* c) {  // stream must be idle
         std::vector<uint32_t> h(c->counters_next);
         HIPC(c, hipMemcpy(h.data(), c->d_counters, (size_t)c->counters_next * 4, hipMemcpyDeviceToHost));
         for (auto& b : c->pending_counters) {
-            for (uint32_t k = 0; k < b.n_ext; k++) c->stats.extension_rays += h[b.first + k];
-            for (uint32_t k = 0; k < b.n_sh; k++) c->stats.shadow_rays += h[b.first + b.n_ext + k];
+            for (uint32_t k = 0; k < b.n_pairs; k++) {
+                c->stats.extension_rays += h[b.first + 2 * k];
+                c->stats.shadow_rays += h[b.first + 2 * k + 1];
+            }
         }
         c->pending_counters.clear();
     }
@@ -440,20 +442,23 @@ int pass_reference_mode(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y,
         const uint32_t nsb = std::min(sb, Sspp - s0);
         const uint32_t n_first = nsb * npix;
         uint32_t first;
-        if (int r = reserve_counters(c, 4 * B, &first)) return r;
-        uint32_t* ext_cnt = c->d_counters + first;   // [b] = extension rays emitted at bounce b (b < B-1)
-        uint32_t* sh_cnt = c->d_counters + first + B;  // [b] = shadow rays emitted at bounce b
+        if (int r = reserve_counters(c, 4 * B + 1, &first)) return r;
+        first += first & 1u;  // 8-byte aligned pairs
+        // pair b = {extension rays emitted at bounce b (b < B-1), shadow rays emitted at bounce b}; then the ray-pool cursors
+        uint32_t* pairs = c->d_counters + first;
         uint32_t* pool_cur = c->d_counters + first + 2 * B;  // [b], [B + b]: ray-pool cursors of the k_extend / k_shadow launch of bounce b
-        c->pending_counters.push_back(CounterBlock{first, B, B});
+        c->pending_counters.push_back(CounterBlock{first, B});
+#define ext_cnt_at(b) (pairs + 2 * (b))
+#define sh_cnt_at(b) (pairs + 2 * (b) + 1)
         int cur = 0;
         for (uint32_t bn = 0; bn < B; bn++) {
             ShadeLaunch L;
             L.g = gd; L.sc = sc; L.pixels = pl->dev; L.pixbn = pl->dev_bn; L.npix = npix; L.width = W; L.s0 = s0; L.bounce = bn;
             L.gbuffer = gb->ptr; L.depth = (const float*)dp->ptr;
             L.in_rays = c->rays[cur]; L.in_hits = c->hits; L.in_T = c->T[cur]; L.in_pid = c->pid[cur];
-            L.in_count = bn ? ext_cnt + (bn - 1) : nullptr; L.n_first = n_first;
-            L.out_rays = c->rays[cur ^ 1]; L.out_T = c->T[cur ^ 1]; L.out_pid = c->pid[cur ^ 1]; L.out_count = ext_cnt + bn;
-            L.sh_rays = c->sh_rays; L.sh_contrib = c->sh_contrib; L.sh_pid = c->sh_pid; L.sh_count = sh_cnt + bn;
+            L.in_count = bn ? ext_cnt_at(bn - 1) : nullptr; L.n_first = n_first;
+            L.out_rays = c->rays[cur ^ 1]; L.out_T = c->T[cur ^ 1]; L.out_pid = c->pid[cur ^ 1]; L.out_count = ext_cnt_at(bn);
+            L.sh_rays = c->sh_rays; L.sh_contrib = c->sh_contrib; L.sh_pid = c->sh_pid; L.sh_count = sh_cnt_at(bn);
             L.lacc = c->lacc; L.stride = S; L.max_n = n_first;
             {
                 ScopedTimer t(c, CAT_SHADE);
@@ -467,17 +472,17 @@ int pass_reference_mode(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y,
             const bool fuse = c->opt_fused_trace == 1 || (c->opt_fused_trace < 0 && n_first <= (96u << 20));
             if (nee && bn != B - 1 && fuse) {
                 ScopedTimer t(c, CAT_TRACE);
-                launch_trace(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->rays[cur], c->sh_rays, S, ext_cnt + bn, sh_cnt + bn, n_first,
+                launch_trace(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->rays[cur], c->sh_rays, S, ext_cnt_at(bn), sh_cnt_at(bn), n_first,
                              c->hits, c->sh_contrib, c->lacc, c->opt_count ? c->d_totals + 4 : nullptr, pool_cur + bn, pool_cur + B + bn);
             } else {
                 if (nee) {
                     ScopedTimer t(c, CAT_SHADOW);
-                    launch_shadow(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->sh_rays, S, sh_cnt + bn, 0, n_first, c->sh_contrib, c->sh_pid,
+                    launch_shadow(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->sh_rays, S, sh_cnt_at(bn), 0, n_first, c->sh_contrib, c->sh_pid,
                                   c->lacc, S, nullptr, nullptr, nullptr, c->opt_count ? c->d_totals + 2 : nullptr, pool_cur + B + bn);
                 }
                 if (bn != B - 1) {
                     ScopedTimer t(c, CAT_EXTEND);
-                    launch_extend(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->rays[cur], S, ext_cnt + bn, 0, n_first, c->hits, nullptr, nullptr,
+                    launch_extend(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->rays[cur], S, ext_cnt_at(bn), 0, n_first, c->hits, nullptr, nullptr,
                                   c->opt_count ? c->d_totals : nullptr, pool_cur + bn);
                 }
             }

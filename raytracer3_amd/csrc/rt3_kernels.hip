@@ -496,7 +496,7 @@ constexpr int kShadeBlock = 512;
 struct BlockAppend {
     uint32_t ext, sh;
 };
-__device__ __forceinline__ BlockAppend block_append2(bool want_ext, uint32_t* ext_counter, bool want_sh, uint32_t* sh_counter,
+__device__ __forceinline__ BlockAppend block_append2(bool want_ext, bool want_sh, unsigned long long* pair /* {ext count, shadow count} */,
                                                      uint32_t* lds /* 2 * (waves + 1) words */) {
     constexpr int kWaves = kShadeBlock / 64;
     const uint32_t lane = __lane_id(), wave = threadIdx.x >> 6;
@@ -516,10 +516,12 @@ __device__ __forceinline__ BlockAppend block_append2(bool want_ext, uint32_t* ex
             te += ce;
             ts += cs;
         }
-        uint32_t be = te ? atomicAdd(ext_counter, te) : 0u;
-        uint32_t bs = ts ? atomicAdd(sh_counter, ts) : 0u;
-        lds[kWaves] = be;
-        lds[2 * kWaves + 1] = bs;
+        // both queue sizes live in one 8-byte word and move with ONE returning atomic (they used to be two atomics on the same
+        // cache line, i.e. on the same L2 atomic unit: the unit's throughput is what a 256-thread block size ran into)
+        unsigned long long old = 0ull;
+        if (te | ts) old = atomicAdd(pair, (unsigned long long)te | ((unsigned long long)ts << 32));
+        lds[kWaves] = (uint32_t)old;
+        lds[2 * kWaves + 1] = (uint32_t)(old >> 32);
     }
     __syncthreads();
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -740,7 +742,7 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
                 emit_ext = true;                  // :53
             }
         }
-        const BlockAppend slot = block_append2(emit_ext, a.out_count, emit_shadow, a.sh_count, append_lds[parity]);
+        const BlockAppend slot = block_append2(emit_ext, emit_shadow, reinterpret_cast<unsigned long long*>(a.out_count), append_lds[parity]);  // out_count, sh_count: one pair
         parity ^= 1u;
         if (emit_shadow) {
             const uint32_t j = slot.sh;
