@@ -30,6 +30,25 @@ sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
 
+def usable_cpus() -> int:
+    """Host cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container on a 256-thread
+    host may be limited to far fewer; threads beyond the quota are only throttled)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]  # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+            p = int(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+            if q > 0 and p > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, 256))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,7 +232,7 @@ def main():
         cw, ch = min(cw, W), min(ch, H)
         x0, y0 = (W - cw) // 2, (H - ch) // 2
         rect = (x0, y0, x0 + cw, y0 + ch)
-        threads = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 256)
+        threads = usable_cpus()
         osc = orc.Scene(mesh, sky, bn, leaf_size=args.leaf_size or 2, node_width=args.node_width or 4, quantized=(1 if args.node_quant < 0 else args.node_quant))
         og = orc.GConst()
         C.memmove(C.byref(og), C.byref(g_last), 304)
