@@ -26,6 +26,7 @@ import time
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
+DEFAULT_SAH_TOP = 2  # the library's RT3_OPT_SAH_TOP default (the oracle of the parity leg is built the same way)
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
@@ -65,6 +66,7 @@ def main():
     ap.add_argument("--node-quant", type=int, default=-1, help="0 | 1 (-1 = library default)")
     ap.add_argument("--refill", type=int, default=-1, help="traversal tuning: idle lanes before a wave refills (RT3_OPT_EXTEND_VARIANT)")
     ap.add_argument("--fused-trace", type=int, default=-1, help="RT3_OPT_FUSED_TRACE: 1 one k_trace launch per bounce, 0 separate k_shadow / k_extend, -1 library default (by launch size)")
+    ap.add_argument("--sah-top", type=int, default=-1, help="RT3_OPT_SAH_TOP: cluster size T of the SAH top (0 = plain LBVH, -1 = library default)")
     ap.add_argument("--pool-chunk", type=int, default=0, help="traversal tuning: rays per pool grab (RT3_OPT_POOL_CHUNK)")
     ap.add_argument("--flags", type=int, default=-1, help="GConst.pad[0] feature flags (-1 = the full estimator); experiments only")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -72,7 +74,7 @@ def main():
     args = ap.parse_args()
     default_workload = (args.gpus == 1 and (args.width, args.height, args.spp, args.bounces, args.detail) == (1920, 1080, 64, 4, 1.0)
                         and args.batch_spp == 0 and args.leaf_size == 0 and args.node_width == 0 and args.node_quant == -1
-                        and args.refill == -1 and args.flags == -1 and args.pool_chunk == 0 and args.fused_trace == -1)
+                        and args.refill == -1 and args.flags == -1 and args.pool_chunk == 0 and args.fused_trace == -1 and args.sah_top == -1)
 
     import numpy as np
     import torch
@@ -118,6 +120,8 @@ def main():
         pt.ctx.set_option(L.OPT_EXTEND_VARIANT, args.refill)
     if args.pool_chunk:
         pt.ctx.set_option(L.OPT_POOL_CHUNK, args.pool_chunk)
+    if args.sah_top >= 0:
+        pt.ctx.set_option(L.OPT_SAH_TOP, args.sah_top)
     if args.fused_trace >= 0:
         pt.ctx.set_option(L.OPT_FUSED_TRACE, args.fused_trace)
     pt.set_scene(mesh, sky, bn)
@@ -233,7 +237,7 @@ def main():
         x0, y0 = (W - cw) // 2, (H - ch) // 2
         rect = (x0, y0, x0 + cw, y0 + ch)
         threads = usable_cpus()
-        osc = orc.Scene(mesh, sky, bn, leaf_size=args.leaf_size or 2, node_width=args.node_width or 4, quantized=(1 if args.node_quant < 0 else args.node_quant))
+        osc = orc.Scene(mesh, sky, bn, leaf_size=args.leaf_size or 2, node_width=args.node_width or 4, quantized=(1 if args.node_quant < 0 else args.node_quant), sah_top=(DEFAULT_SAH_TOP if args.sah_top < 0 else args.sah_top))
         og = orc.GConst()
         C.memmove(C.byref(og), C.byref(g_last), 304)
         ogb, odepth = osc.gbuffer(og, rect=rect, threads=threads)

@@ -124,6 +124,8 @@ int rt3_device_name(rt3_ctx *ctx, char *buf, size_t buf_size);
 #define RT3_OPT_POOL_CHUNK 9      /* traversal tuning: rays a wave takes from the launch's ray pool per grab (default 256) */
 #define RT3_OPT_FUSED_TRACE 10    /* 1: one k_trace launch per bounce for extension + shadow rays; 0: separate k_shadow and k_extend launches;
                                      -1 (default): fused for batches of at most 96 Mi paths (a frame split over several GPUs), where launches are short */
+#define RT3_OPT_SAH_TOP 11       /* T > 0 (default 2): the tree above Karras subtrees of at most T triangles is re-linked by binned SAH on the
+                                     host (the reference asks its driver for PREFER_FAST_TRACE builds, raytracing.rs:103,131); 0 = plain GPU LBVH */
 int rt3_set_option(rt3_ctx *ctx, int option, int64_t value);
 
 /* ---- scene upload: DynamicBuffer::push (vulkan/buffer.rs:406-420) into the world buffers of

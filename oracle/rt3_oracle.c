@@ -403,7 +403,7 @@ struct orc_scene {
     orc_geometry_info *geoms; uint32_t *prim_counts, *first_prim; uint32_t n_geoms;
     uint32_t n_prims; uint32_t *prim_geom;
     /* accel */
-    uint32_t n_tris, n_nodes, max_depth, leaf_max, node_width, node_quant, collapse;
+    uint32_t n_tris, n_nodes, max_depth, leaf_max, node_width, node_quant, collapse, sah_top;
     float *nodes;   /* 16 words per node */
     float *tris;    /* 12 words per tri (Morton order) */
     uint64_t *codes;
@@ -423,6 +423,7 @@ orc_scene *orc_scene_create(void) {
     s->node_width = 4;
     s->node_quant = 1;
     s->collapse = 1;
+    s->sah_top = 2;
     for (int i = 0; i < 256; i++) { /* sRGB EOTF, IEC 61966-2-1, in double */
         double c = i / 255.0;
         s->srgb_lut[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
@@ -436,6 +437,7 @@ void orc_accel_set_layout(orc_scene *s, uint32_t leaf_max, uint32_t node_width, 
     s->node_quant = s->node_width == 4 ? (quantized > 2 ? 2 : quantized) : 0; /* 0 fp32 128 B, 1 quantised 64 B, 2 compact 48 B */
 }
 void orc_accel_set_collapse(orc_scene *s, uint32_t mode) { s->collapse = mode ? 1u : 0u; }
+void orc_accel_set_sah_top(orc_scene *s, uint32_t cluster_size) { s->sah_top = cluster_size; }
 uint32_t orc_accel_node_words(const orc_scene *s) { return s->node_width == 2 ? 16u : (s->node_quant == 2 ? 12u : (s->node_quant ? 16u : 32u)); }
 
 /* [north_star] 64-byte four-wide node with quantised child boxes:
@@ -672,6 +674,103 @@ static int delta_fn(const uint64_t *codes, int n, int i, int j) {
     if (a != b) return __builtin_clzll(a ^ b);
     return 64 + __builtin_clz((uint32_t)i ^ (uint32_t)j);
 }
+/* ---- SAH top (hierarchical LBVH, after Pantaleoni & Luebke 2010 / Garanzha et al. 2011): the Karras tree is kept below
+ * "cluster roots" (maximal subtrees of at most T triangles: contiguous Morton ranges); the C - 1 nodes above the C cluster roots
+ * are re-linked into a tree built top-down by binned SAH (16 bins on the cluster centroids, cost = half area x triangle count)
+ * over the cluster boxes.  Node indices are reused (the top of a binary tree with C leaves has C - 1 nodes), the root stays
+ * node 0.  fp32 in a fixed order; the product's host code (rt3_lbvh.hip, sah_top_relink) runs the same algorithm. */
+typedef struct { uint32_t ref, cnt; float mn[3], mx[3]; } sah_cluster;
+static inline float half_area3(const float mn[3], const float mx[3]) {
+    float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
+    return (ex * ey + ey * ez) + ez * ex;
+}
+static void sah_top_rebuild(uint32_t nn, uint32_t *left, uint32_t *right, uint32_t *rlo, uint32_t *rcnt, const float *lmin, const float *lmax,
+                            const float *nmin, const float *nmax, uint32_t T) {
+    uint32_t nc = 0, np = 0;
+    sah_cluster *cl = (sah_cluster *)malloc(((size_t)nn + 2) * sizeof(sah_cluster));
+    uint32_t *pool = (uint32_t *)malloc((size_t)nn * 4);
+    for (uint32_t i = 0; i < nn; i++) {
+        if (!(i == 0 || rcnt[i] > T)) continue;
+        pool[np++] = i;
+        uint32_t c2[2] = {left[i], right[i]};
+        for (int c = 0; c < 2; c++) {
+            uint32_t ch = c2[c];
+            if (!(ch & 0x80000000u) && rcnt[ch] > T) continue;
+            sah_cluster *k = &cl[nc++];
+            k->ref = ch;
+            if (ch & 0x80000000u) { uint32_t q = ch & 0x7FFFFFFFu; k->cnt = 1; memcpy(k->mn, lmin + 3 * q, 12); memcpy(k->mx, lmax + 3 * q, 12); }
+            else { k->cnt = rcnt[ch]; memcpy(k->mn, nmin + 3 * ch, 12); memcpy(k->mx, nmax + 3 * ch, 12); }
+        }
+    }
+    if (nc < 3 || np != nc - 1) { free(cl); free(pool); return; }
+    uint32_t *idx = (uint32_t *)malloc((size_t)nc * 4), *tmp = (uint32_t *)malloc((size_t)nc * 4);
+    for (uint32_t i = 0; i < nc; i++) idx[i] = i;
+    typedef struct { uint32_t a, n, patch; } job;
+    job *st = (job *)malloc((size_t)nc * 2 * sizeof(job) + 64);
+    int sp = 0; uint32_t next_pool = 0;
+    st[sp++] = (job){0, nc, 0xFFFFFFFFu};
+    while (sp > 0) {
+        job j = st[--sp];
+        uint32_t ref;
+        if (j.n == 1) ref = cl[idx[j.a]].ref;
+        else {
+            uint32_t node = pool[next_pool++];
+            ref = node;
+            float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+            uint32_t total = 0;
+            for (uint32_t k = 0; k < j.n; k++) {
+                const sah_cluster *c = &cl[idx[j.a + k]];
+                total += c->cnt;
+                for (int a = 0; a < 3; a++) { float ce = (c->mn[a] + c->mx[a]) * 0.5f; cmn[a] = fminx(cmn[a], ce); cmx[a] = fmaxx(cmx[a], ce); }
+            }
+            float best_cost = INFINITY; int best_axis = -1, best_split = 0;
+            for (int a = 0; a < 3; a++) {
+                float ext = cmx[a] - cmn[a];
+                if (!(ext > 0.0f)) continue;
+                float bmn[16][3], bmx[16][3]; uint32_t bc[16];
+                for (int b = 0; b < 16; b++) { bc[b] = 0; for (int q = 0; q < 3; q++) { bmn[b][q] = INFINITY; bmx[b][q] = -INFINITY; } }
+                for (uint32_t k = 0; k < j.n; k++) {
+                    const sah_cluster *c = &cl[idx[j.a + k]];
+                    float ce = (c->mn[a] + c->mx[a]) * 0.5f;
+                    int b = (int)(((ce - cmn[a]) / ext) * 16.0f); if (b > 15) b = 15;
+                    bc[b] += c->cnt;
+                    for (int q = 0; q < 3; q++) { bmn[b][q] = fminx(bmn[b][q], c->mn[q]); bmx[b][q] = fmaxx(bmx[b][q], c->mx[q]); }
+                }
+                float rmn[16][3], rmx[16][3]; uint32_t rc[16];
+                for (int b = 15; b >= 0; b--) {
+                    for (int q = 0; q < 3; q++) { rmn[b][q] = b == 15 ? bmn[b][q] : fminx(bmn[b][q], rmn[b + 1][q]); rmx[b][q] = b == 15 ? bmx[b][q] : fmaxx(bmx[b][q], rmx[b + 1][q]); }
+                    rc[b] = bc[b] + (b == 15 ? 0u : rc[b + 1]);
+                }
+                float lmn[3] = {INFINITY, INFINITY, INFINITY}, lmx[3] = {-INFINITY, -INFINITY, -INFINITY}; uint32_t lc = 0;
+                for (int sgl = 1; sgl < 16; sgl++) {
+                    for (int q = 0; q < 3; q++) { lmn[q] = fminx(lmn[q], bmn[sgl - 1][q]); lmx[q] = fmaxx(lmx[q], bmx[sgl - 1][q]); }
+                    lc += bc[sgl - 1];
+                    if (lc == 0 || rc[sgl] == 0) continue;
+                    float cost = half_area3(lmn, lmx) * (float)lc + half_area3(rmn[sgl], rmx[sgl]) * (float)rc[sgl];
+                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = sgl; }
+                }
+            }
+            uint32_t nl = 0;
+            if (best_axis < 0) nl = j.n / 2;
+            else {
+                float ext = cmx[best_axis] - cmn[best_axis]; uint32_t w = 0, r = 0;
+                for (uint32_t k = 0; k < j.n; k++) {
+                    const sah_cluster *c = &cl[idx[j.a + k]];
+                    float ce = (c->mn[best_axis] + c->mx[best_axis]) * 0.5f;
+                    int b = (int)(((ce - cmn[best_axis]) / ext) * 16.0f); if (b > 15) b = 15;
+                    if (b < best_split) idx[j.a + w++] = idx[j.a + k]; else tmp[r++] = idx[j.a + k];
+                }
+                memcpy(idx + j.a + w, tmp, (size_t)r * 4);
+                nl = w;
+            }
+            rcnt[node] = total > T ? total : T + 1u; rlo[node] = 0; /* a re-linked node is never a multi-triangle leaf: its triangles are not contiguous */
+            st[sp++] = (job){j.a + nl, j.n - nl, (node << 1) | 1u};
+            st[sp++] = (job){j.a, nl, (node << 1)};
+        }
+        if (j.patch != 0xFFFFFFFFu) { if (j.patch & 1u) right[j.patch >> 1] = ref; else left[j.patch >> 1] = ref; }
+    }
+    free(cl); free(pool); free(idx); free(tmp); free(st);
+}
 /* child slots of four-wide node i under the surface-area collapse (see orc_accel_build); half area = (ex*ey + ey*ez) + ez*ex */
 static uint32_t sah_slots(uint32_t i, const uint32_t *left, const uint32_t *right, const uint32_t *rcnt, const float *nmin, const float *nmax,
                           uint32_t K, uint32_t sl[4]) {
@@ -794,6 +893,8 @@ int orc_accel_build(orc_scene *s) {
         uint32_t *stack = (uint32_t *)malloc((size_t)nn * 2 * 4 + 64);
         uint8_t *state = (uint8_t *)calloc(nn, 1);
         uint32_t *depth = (uint32_t *)calloc(nn, 4);
+        for (int pass = 0; pass < 2; pass++) {
+        memset(state, 0, nn); memset(depth, 0, (size_t)nn * 4);
         int sp = 0;
         stack[sp++] = 0;
         while (sp > 0) {
@@ -809,6 +910,8 @@ int orc_accel_build(orc_scene *s) {
                 const float *bmn = (r & 0x80000000u) ? lmin + 3 * (r & 0x7FFFFFFFu) : nmin + 3 * r, *bmx = (r & 0x80000000u) ? lmax + 3 * (r & 0x7FFFFFFFu) : nmax + 3 * r;
                 for (int j = 0; j < 3; j++) { nmin[3 * i + j] = fminx(amn[j], bmn[j]); nmax[3 * i + j] = fmaxx(amx[j], bmx[j]); }
             }
+        }
+        if (pass == 0) { if (!s->sah_top) break; sah_top_rebuild(nn, left, right, rlo, rcnt, lmin, lmax, nmin, nmax, s->sah_top > s->leaf_max ? s->sah_top : s->leaf_max); }
         }
         /* Multi-triangle leaves: an internal node covering <= leaf_max triangles (contiguous in Morton order) is referenced
          * as a leaf {bit 31, count-1 in bits 30..28, first triangle in bits 27..0}; the root always stays a node.

@@ -109,6 +109,8 @@ int orc_scene_set_texture(orc_scene *s, uint32_t index, const uint8_t *rgba_srgb
 void orc_accel_set_layout(orc_scene *s, uint32_t leaf_max, uint32_t node_width, uint32_t quantized);
 /* four-wide collapse rule: 1 = surface-area greedy (default), 0 = even binary depth */
 void orc_accel_set_collapse(orc_scene *s, uint32_t mode);
+/* SAH top: the tree above Karras subtrees of at most cluster_size triangles is re-linked by binned SAH (0 = plain LBVH; default 2) */
+void orc_accel_set_sah_top(orc_scene *s, uint32_t cluster_size);
 uint32_t orc_accel_node_words(const orc_scene *s);
 int orc_accel_build(orc_scene *s);
 uint32_t orc_accel_num_tris(const orc_scene *s);

@@ -97,7 +97,7 @@ struct rt3_ctx {
     int64_t opt_batch_spp = 0;
     bool opt_profile = false, opt_count = false;
     int opt_variant = 0;  // RT3_OPT_EXTEND_VARIANT: reserved for traversal experiments
-    uint32_t opt_leaf_size = 2, opt_node_width = 4, opt_node_quant = 1, opt_collapse = 1;
+    uint32_t opt_leaf_size = 2, opt_node_width = 4, opt_node_quant = 1, opt_collapse = 1, opt_sah_top = 2;
     int opt_fused_trace = -1;  // -1 auto (by launch size), 0 off, 1 on
     rt3_stats stats;
     uint64_t primary_rays_pending = 0;
@@ -598,6 +598,11 @@ int rt3_set_option(rt3_ctx* c, int option, int64_t value) {
             c->opt_node_quant = (uint32_t)value;
             c->accel_built = false;
             return RT3_OK;
+        case RT3_OPT_SAH_TOP:
+            if (value < 0 || value > 65536) return fail(c, RT3_E_INVALID, "SAH-top cluster size must be 0 (off) .. 65536");
+            c->opt_sah_top = (uint32_t)value;
+            c->accel_built = false;
+            return RT3_OK;
         case RT3_OPT_FUSED_TRACE:
             if (value < -1 || value > 1) return fail(c, RT3_E_INVALID, "fused trace must be -1 (auto), 0 or 1");
             c->opt_fused_trace = (int)value;
@@ -822,7 +827,7 @@ int rt3_accel_build(rt3_ctx* c, uint32_t* out_handle) {
     dev_free(c->bvh.tris);
     dev_free(c->bvh.tri_shade);
     hipError_t e = lbvh_build(c->stream, c->d_verts, c->d_indices, c->d_geoms, c->d_prim_geom, c->d_first_prim, c->n_prims, c->opt_leaf_size,
-                              c->opt_node_width, c->opt_node_quant, c->opt_collapse, &c->bvh);
+                              c->opt_node_width, c->opt_node_quant, c->opt_collapse, c->opt_sah_top, &c->bvh);
     if (e != hipSuccess) return fail(c, RT3_E_HIP, std::string("lbvh_build: ") + hipGetErrorString(e));
     // worst-case stack use of the near-first walk: (children per node - 1) entries per level above the leaves
     const uint32_t stack_need = c->bvh.max_depth > 1 ? (c->opt_node_width - 1) * (c->bvh.max_depth - 1) : 0;

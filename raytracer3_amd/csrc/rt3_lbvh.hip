@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <vector>
+
 #include "rt3_device.hpp"
 #include "rt3_internal.hpp"
 
@@ -545,6 +547,150 @@ __global__ void k_single(const float* lmin, const float* lmax, int wide, int qua
     }
 }
 
+// ---- SAH top (hierarchical LBVH, after Pantaleoni & Luebke 2010 / Garanzha et al. 2011), on the host.  The Karras tree is kept
+// below "cluster roots" (maximal subtrees of at most T triangles: contiguous Morton ranges); the C - 1 nodes above the C cluster
+// roots are re-linked into a tree built top-down by binned SAH (16 bins on the cluster centroids, cost = half area x triangle
+// count) over the cluster boxes.  Node indices are reused (the top of a binary tree with C leaves has C - 1 nodes), the root
+// stays node 0.  fp32 in a fixed order, the oracle runs the same algorithm.  A re-linked node is never a multi-triangle leaf
+// (its triangles are not contiguous), so its count is kept above T.
+namespace {
+struct SahCluster {
+    uint32_t ref, cnt;
+    float mn[3], mx[3];
+};
+inline float half_area3(const float* mn, const float* mx) {
+    const float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
+    return (ex * ey + ey * ez) + ez * ex;
+}
+inline float fminh(float a, float b) { return a < b ? a : b; }
+inline float fmaxh(float a, float b) { return a > b ? a : b; }
+// left / right / rcnt: the Karras tree (modified in place); parents are rewritten for every re-linked edge
+bool sah_top_relink(uint32_t nn, std::vector<uint32_t>& left, std::vector<uint32_t>& right, std::vector<uint32_t>& rcnt, std::vector<uint32_t>& pint,
+                    std::vector<uint32_t>& pleaf, const std::vector<float>& lmin, const std::vector<float>& lmax, const std::vector<float>& nbox,
+                    uint32_t T) {
+    std::vector<SahCluster> cl;
+    std::vector<uint32_t> pool;
+    for (uint32_t i = 0; i < nn; i++) {
+        if (!(i == 0 || rcnt[i] > T)) continue;
+        pool.push_back(i);
+        const uint32_t c2[2] = {left[i], right[i]};
+        for (int c = 0; c < 2; c++) {
+            const uint32_t ch = c2[c];
+            if (!(ch & 0x80000000u) && rcnt[ch] > T) continue;  // another top node
+            SahCluster k;
+            k.ref = ch;
+            if (ch & 0x80000000u) {
+                const uint32_t q = ch & 0x7FFFFFFFu;
+                k.cnt = 1;
+                for (int a = 0; a < 3; a++) { k.mn[a] = lmin[3 * (size_t)q + a]; k.mx[a] = lmax[3 * (size_t)q + a]; }
+            } else {
+                k.cnt = rcnt[ch];
+                for (int a = 0; a < 3; a++) { k.mn[a] = nbox[6 * (size_t)ch + a]; k.mx[a] = nbox[6 * (size_t)ch + 3 + a]; }
+            }
+            cl.push_back(k);
+        }
+    }
+    const uint32_t nc = (uint32_t)cl.size();
+    if (nc < 3 || pool.size() != nc - 1) return false;
+    std::vector<uint32_t> idx(nc), tmp(nc);
+    for (uint32_t i = 0; i < nc; i++) idx[i] = i;
+    struct Job { uint32_t a, n, patch; };
+    std::vector<Job> st;
+    st.push_back(Job{0, nc, 0xFFFFFFFFu});
+    uint32_t next_pool = 0;
+    const float inf = INFINITY;
+    while (!st.empty()) {
+        const Job j = st.back();
+        st.pop_back();
+        uint32_t ref;
+        if (j.n == 1) {
+            ref = cl[idx[j.a]].ref;
+        } else {
+            const uint32_t node = pool[next_pool++];
+            ref = node;
+            float cmn[3] = {inf, inf, inf}, cmx[3] = {-inf, -inf, -inf};
+            uint32_t total = 0;
+            for (uint32_t k = 0; k < j.n; k++) {
+                const SahCluster& c = cl[idx[j.a + k]];
+                total += c.cnt;
+                for (int a = 0; a < 3; a++) {
+                    const float ce = (c.mn[a] + c.mx[a]) * 0.5f;
+                    cmn[a] = fminh(cmn[a], ce);
+                    cmx[a] = fmaxh(cmx[a], ce);
+                }
+            }
+            float best_cost = inf;
+            int best_axis = -1, best_split = 0;
+            for (int a = 0; a < 3; a++) {
+                const float ext = cmx[a] - cmn[a];
+                if (!(ext > 0.0f)) continue;
+                float bmn[16][3], bmx[16][3];
+                uint32_t bc[16];
+                for (int b = 0; b < 16; b++) {
+                    bc[b] = 0;
+                    for (int q = 0; q < 3; q++) { bmn[b][q] = inf; bmx[b][q] = -inf; }
+                }
+                for (uint32_t k = 0; k < j.n; k++) {
+                    const SahCluster& c = cl[idx[j.a + k]];
+                    const float ce = (c.mn[a] + c.mx[a]) * 0.5f;
+                    int b = (int)(((ce - cmn[a]) / ext) * 16.0f);
+                    if (b > 15) b = 15;
+                    bc[b] += c.cnt;
+                    for (int q = 0; q < 3; q++) { bmn[b][q] = fminh(bmn[b][q], c.mn[q]); bmx[b][q] = fmaxh(bmx[b][q], c.mx[q]); }
+                }
+                float rmn[16][3], rmx[16][3];
+                uint32_t rc[16];
+                for (int b = 15; b >= 0; b--) {
+                    for (int q = 0; q < 3; q++) {
+                        rmn[b][q] = b == 15 ? bmn[b][q] : fminh(bmn[b][q], rmn[b + 1][q]);
+                        rmx[b][q] = b == 15 ? bmx[b][q] : fmaxh(bmx[b][q], rmx[b + 1][q]);
+                    }
+                    rc[b] = bc[b] + (b == 15 ? 0u : rc[b + 1]);
+                }
+                float lmn[3] = {inf, inf, inf}, lmx[3] = {-inf, -inf, -inf};
+                uint32_t lc = 0;
+                for (int sp = 1; sp < 16; sp++) {
+                    for (int q = 0; q < 3; q++) { lmn[q] = fminh(lmn[q], bmn[sp - 1][q]); lmx[q] = fmaxh(lmx[q], bmx[sp - 1][q]); }
+                    lc += bc[sp - 1];
+                    if (lc == 0 || rc[sp] == 0) continue;
+                    const float cost = half_area3(lmn, lmx) * (float)lc + half_area3(rmn[sp], rmx[sp]) * (float)rc[sp];
+                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = sp; }
+                }
+            }
+            uint32_t nl = 0;
+            if (best_axis < 0) {
+                nl = j.n / 2;  // coincident centroids: halve in index order
+            } else {           // stable partition by bin
+                const float ext = cmx[best_axis] - cmn[best_axis];
+                uint32_t w = 0, r = 0;
+                for (uint32_t k = 0; k < j.n; k++) {
+                    const SahCluster& c = cl[idx[j.a + k]];
+                    const float ce = (c.mn[best_axis] + c.mx[best_axis]) * 0.5f;
+                    int b = (int)(((ce - cmn[best_axis]) / ext) * 16.0f);
+                    if (b > 15) b = 15;
+                    if (b < best_split) idx[j.a + w++] = idx[j.a + k];
+                    else tmp[r++] = idx[j.a + k];
+                }
+                for (uint32_t k = 0; k < r; k++) idx[j.a + w + k] = tmp[k];
+                nl = w;
+            }
+            rcnt[node] = total > T ? total : T + 1u;
+            st.push_back(Job{j.a + nl, j.n - nl, (node << 1) | 1u});  // right first: the left subtree is numbered first (pre-order)
+            st.push_back(Job{j.a, nl, node << 1});
+        }
+        if (j.patch != 0xFFFFFFFFu) {
+            const uint32_t parent = j.patch >> 1;
+            if (j.patch & 1u) right[parent] = ref;
+            else left[parent] = ref;
+            if (ref & 0x80000000u) pleaf[ref & 0x7FFFFFFFu] = parent;
+            else pint[ref] = parent;
+        }
+    }
+    pint[0] = 0xFFFFFFFFu;
+    return true;
+}
+}  // namespace
+
 #define LB_CHECK(x)                  \
     do {                             \
         hipError_t e_ = (x);         \
@@ -556,7 +702,7 @@ __global__ void k_single(const float* lmin, const float* lmax, int wide, int qua
 
 hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,
                       const uint32_t* first_prim, uint32_t n, uint32_t leaf_max, uint32_t node_width, uint32_t node_quant, uint32_t collapse_mode,
-                      LbvhResult* out) {
+                      uint32_t sah_top, LbvhResult* out) {
     hipError_t err = hipSuccess;
     *out = LbvhResult{};
     out->n_tris = n;
@@ -633,6 +779,29 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
     } else {
         hipLaunchKernelGGL(k_hierarchy, dim3(grid), dim3(256), 0, st, keys_out, (int)n, left, right, pint, pleaf, rlo, rcnt);
         hipLaunchKernelGGL(k_refit, dim3(grid), dim3(256), 0, st, left, right, pint, pleaf, lmin, lmax, n, nbox, arrive);
+        if (sah_top) {  // re-link the upper tree by SAH on the host, then refit again
+            const uint32_t T = sah_top > leaf_max ? sah_top : leaf_max;
+            std::vector<uint32_t> h_left(nn), h_right(nn), h_rcnt(nn), h_pint(nn), h_pleaf(n);
+            std::vector<float> h_lmin((size_t)n * 3), h_lmax((size_t)n * 3), h_nbox((size_t)nn * 6);
+            LB_CHECK(hipStreamSynchronize(st));
+            LB_CHECK(hipMemcpy(h_left.data(), left, (size_t)nn * 4, hipMemcpyDeviceToHost));
+            LB_CHECK(hipMemcpy(h_right.data(), right, (size_t)nn * 4, hipMemcpyDeviceToHost));
+            LB_CHECK(hipMemcpy(h_rcnt.data(), rcnt, (size_t)nn * 4, hipMemcpyDeviceToHost));
+            LB_CHECK(hipMemcpy(h_pint.data(), pint, (size_t)nn * 4, hipMemcpyDeviceToHost));
+            LB_CHECK(hipMemcpy(h_pleaf.data(), pleaf, (size_t)n * 4, hipMemcpyDeviceToHost));
+            LB_CHECK(hipMemcpy(h_lmin.data(), lmin, (size_t)n * 12, hipMemcpyDeviceToHost));
+            LB_CHECK(hipMemcpy(h_lmax.data(), lmax, (size_t)n * 12, hipMemcpyDeviceToHost));
+            LB_CHECK(hipMemcpy(h_nbox.data(), nbox, (size_t)nn * 24, hipMemcpyDeviceToHost));
+            if (sah_top_relink(nn, h_left, h_right, h_rcnt, h_pint, h_pleaf, h_lmin, h_lmax, h_nbox, T)) {
+                LB_CHECK(hipMemcpy(left, h_left.data(), (size_t)nn * 4, hipMemcpyHostToDevice));
+                LB_CHECK(hipMemcpy(right, h_right.data(), (size_t)nn * 4, hipMemcpyHostToDevice));
+                LB_CHECK(hipMemcpy(rcnt, h_rcnt.data(), (size_t)nn * 4, hipMemcpyHostToDevice));
+                LB_CHECK(hipMemcpy(pint, h_pint.data(), (size_t)nn * 4, hipMemcpyHostToDevice));
+                LB_CHECK(hipMemcpy(pleaf, h_pleaf.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+                LB_CHECK(hipMemsetAsync(arrive, 0, (size_t)nn * 4, st));
+                hipLaunchKernelGGL(k_refit, dim3(grid), dim3(256), 0, st, left, right, pint, pleaf, lmin, lmax, n, nbox, arrive);
+            }
+        }
         if (collapse) {
             // top-down, one four-wide level per launch (the frontier of level l+1 is produced by level l); ~log4(n) launches
             uint32_t *fr_a = nullptr, *fr_b = nullptr, *fr_n = nullptr, n_front = 1, wide_levels = 0;

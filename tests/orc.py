@@ -46,6 +46,7 @@ def lib():
             getattr(L, n).argtypes = [vp]
         L.orc_accel_set_layout.argtypes = [vp, u32, u32, u32]
         L.orc_accel_set_collapse.argtypes = [vp, u32]
+        L.orc_accel_set_sah_top.argtypes = [vp, u32]
         L.orc_accel_node_words.restype = u32; L.orc_accel_node_words.argtypes = [vp]
         L.orc_scene_set_vertices.argtypes = [vp, vp, u32]
         L.orc_scene_set_indices.argtypes = [vp, vp, u32]
@@ -85,11 +86,12 @@ def camera_gconst(position, direction, fov_deg, width, height, z_near=0.1, z_far
 
 
 class Scene:
-    def __init__(self, mesh, sky=None, bluenoise=None, build=True, leaf_size=2, node_width=4, quantized=1, collapse=1):
+    def __init__(self, mesh, sky=None, bluenoise=None, build=True, leaf_size=2, node_width=4, quantized=1, collapse=1, sah_top=2):
         L = lib()
         self.h = L.orc_scene_create()
         L.orc_accel_set_layout(self.h, leaf_size, node_width, quantized)
         L.orc_accel_set_collapse(self.h, collapse)
+        L.orc_accel_set_sah_top(self.h, sah_top)
         self.mesh = mesh
         v = np.ascontiguousarray(mesh.vertices, np.float32); i = np.ascontiguousarray(mesh.indices, np.uint32)
         L.orc_scene_set_vertices(self.h, ptr(v), len(v))

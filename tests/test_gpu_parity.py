@@ -100,6 +100,32 @@ def test_lbvh_even_depth_collapse_still_available(small):
     ctx.close()
 
 
+@pytest.mark.parametrize("T", [0, 8, 64])
+def test_lbvh_sah_top_bit_identical(small, T):
+    """RT3_OPT_SAH_TOP: the tree above Karras subtrees of <= T triangles re-linked by binned SAH on the host -- same arrays as
+    the oracle's restatement, same hits as the plain LBVH, fewer node visits."""
+    mesh, sky, bn, _ = small
+    plain = orc.Scene(mesh, sah_top=0)
+    osc = orc.Scene(mesh, sah_top=T)
+    ctx = Context(0)
+    ctx.set_option(L.OPT_SAH_TOP, T)
+    ctx.upload_mesh(mesh)
+    ctx.build_accel()
+    assert ctx.accel_info()[:3] == (osc.n_nodes, osc.n_tris, osc.max_depth)
+    nodes, tris = ctx.accel_download()
+    assert np.array_equal(nodes, osc.nodes()) and np.array_equal(tris, osc.tris())
+    rays = rays_random(20000, 8, [-14, 0.2, -8], [14, 12, 8])
+    t, u, v, p, cn, ct, _ = ctx.trace_rays(rays, counts=True)
+    ot, ou, ov, op, ocn, oct = osc.trace_closest(rays, counts=True)
+    assert np.array_equal(p, op) and np.array_equal(t[p != L.MISS], ot[p != L.MISS]) and np.array_equal(cn, ocn) and np.array_equal(ct, oct)
+    pt_, pu_, pv_, pp_, pcn, pct = plain.trace_closest(rays, counts=True)
+    assert np.array_equal(pp_, p) and np.array_equal(pt_[p != L.MISS], t[p != L.MISS])
+    if 0 < T <= 8:
+        assert cn.mean() < pcn.mean()
+    assert np.array_equal(ctx.trace_rays(rays, any_hit=True)[3] != 0, osc.trace_any(rays) != 0)
+    ctx.close()
+
+
 def test_lbvh_edge_cases():
     """empty scene, one triangle, duplicate triangles (identical Morton codes)."""
     ctx = Context(0)

@@ -17,7 +17,7 @@ def test_bvh_equals_bruteforce_fp32_and_tracks_fp64():
     mesh = scenes.atrium(0.2)
     sc = orc.Scene(mesh)
     assert sc.n_nodes < sc.n_tris and sc.max_depth < 22
-    base = orc.Scene(mesh, leaf_size=1, node_width=2, quantized=0)  # plain Karras tree: n - 1 binary nodes
+    base = orc.Scene(mesh, leaf_size=1, node_width=2, quantized=0, sah_top=0)  # plain Karras tree: n - 1 binary nodes
     assert base.n_nodes == base.n_tris - 1
     codes = sc.codes()
     assert (np.diff(codes.astype(np.float64)) >= 0).all()  # Morton order
@@ -41,6 +41,10 @@ def test_bvh_equals_bruteforce_fp32_and_tracks_fp64():
         assert np.array_equal(ap, p) and np.array_equal(at, t) and np.array_equal(au, u) and np.array_equal(av, v)
         assert np.array_equal(alt.trace_any(rays) != 0, occ != 0)
     # the surface-area collapse only regroups the same binary tree into better four-wide nodes: same hits, fewer visits
+    lb = orc.Scene(mesh, sah_top=0)
+    lt, lu, lv, lp, lnn, lnt = lb.trace_closest(rays, counts=True)
+    assert np.array_equal(lp, p) and np.array_equal(lt, t) and nn.mean() < lnn.mean()  # SAH top: same hits, fewer visits than the plain LBVH
+    print("nodes/ray: plain LBVH %.2f, SAH top %.2f" % (lnn.mean(), nn.mean()))
     par = orc.Scene(mesh, collapse=0)
     pt_, pu_, pv_, pp_, pnn, pnt = par.trace_closest(rays, counts=True)
     assert np.array_equal(pp_, p) and np.array_equal(pt_, t) and nn.mean() < pnn.mean()
