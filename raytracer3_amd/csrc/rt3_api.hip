@@ -88,7 +88,6 @@ struct rt3_ctx {
     float *rays[2] = {nullptr, nullptr}, *hits = nullptr, *T[2] = {nullptr, nullptr};
     uint32_t* pid[2] = {nullptr, nullptr};
     float *sh_rays = nullptr, *sh_contrib = nullptr, *lacc = nullptr, *radsum = nullptr;
-    uint32_t* sh_pid = nullptr;
     uint32_t* d_counters = nullptr;
     uint32_t counters_cap = 1 << 16, counters_next = 0;
     unsigned long long* d_totals = nullptr;
@@ -256,8 +255,7 @@ int ensure_work(rt3_ctx* c, size_t paths, size_t npix) {
         }
         if (int r = dev_alloc(c, &c->hits, 4 * P)) return r;
         if (int r = dev_alloc(c, &c->sh_rays, 8 * P)) return r;
-        if (int r = dev_alloc(c, &c->sh_contrib, 4 * P)) return r;  // {rgb, path id} records
-        if (int r = dev_alloc(c, &c->sh_pid, P)) return r;
+        if (int r = dev_alloc(c, &c->sh_contrib, 2 * P)) return r;  // {blue contribution, path id} records (red / green ride with the ray)
         if (int r = dev_alloc(c, &c->lacc, 4 * P)) return r;  // float4 per path
         c->cap = P;
     }
@@ -458,7 +456,7 @@ int pass_reference_mode(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y,
             L.in_rays = c->rays[cur]; L.in_hits = c->hits; L.in_T = c->T[cur]; L.in_pid = c->pid[cur];
             L.in_count = bn ? ext_cnt_at(bn - 1) : nullptr; L.n_first = n_first;
             L.out_rays = c->rays[cur ^ 1]; L.out_T = c->T[cur ^ 1]; L.out_pid = c->pid[cur ^ 1]; L.out_count = ext_cnt_at(bn);
-            L.sh_rays = c->sh_rays; L.sh_contrib = c->sh_contrib; L.sh_pid = c->sh_pid; L.sh_count = sh_cnt_at(bn);
+            L.sh_rays = c->sh_rays; L.sh_contrib = c->sh_contrib; L.sh_count = sh_cnt_at(bn);
             L.lacc = c->lacc; L.stride = S; L.max_n = n_first;
             {
                 ScopedTimer t(c, CAT_SHADE);
@@ -477,7 +475,7 @@ int pass_reference_mode(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y,
             } else {
                 if (nee) {
                     ScopedTimer t(c, CAT_SHADOW);
-                    launch_shadow(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->sh_rays, S, sh_cnt_at(bn), 0, n_first, c->sh_contrib, c->sh_pid,
+                    launch_shadow(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->sh_rays, S, sh_cnt_at(bn), 0, n_first, c->sh_contrib, nullptr,
                                   c->lacc, S, nullptr, nullptr, nullptr, c->opt_count ? c->d_totals + 2 : nullptr, pool_cur + B + bn);
                 }
                 if (bn != B - 1) {
@@ -562,7 +560,7 @@ void rt3_destroy(rt3_ctx* c) {
         (void)hipFree(p.dev_bn);
     }
     for (int k = 0; k < 2; k++) { dev_free(c->rays[k]); dev_free(c->T[k]); dev_free(c->pid[k]); }
-    dev_free(c->hits); dev_free(c->sh_rays); dev_free(c->sh_contrib); dev_free(c->sh_pid); dev_free(c->lacc); dev_free(c->radsum);
+    dev_free(c->hits); dev_free(c->sh_rays); dev_free(c->sh_contrib); dev_free(c->lacc); dev_free(c->radsum);
     dev_free(c->d_counters); dev_free(c->d_totals);
     for (auto& t : c->pending_events) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto& t : c->free_events) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }

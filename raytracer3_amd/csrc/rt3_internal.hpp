@@ -43,7 +43,6 @@ struct ShadeLaunch {
     uint32_t* out_count;
     float* sh_rays;
     float* sh_contrib;
-    uint32_t* sh_pid;
     uint32_t* sh_count;
     float* lacc;
     size_t stride;

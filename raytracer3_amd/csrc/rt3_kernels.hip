@@ -83,6 +83,7 @@ struct LaneRay {  // traversal state of the ray a lane currently owns
     Hit best;
     uint32_t cur, leaf_k, index, steps, cn, ct;
     int sp;
+    float pay0, pay1;  // shadow rays of the path tracer's own queue: two words of payload ride in the .w of the two ray records
 };
 
 // MODE 0: closest hit over one queue; 1: any hit over one queue; 2: both queues in one walk -- the lanes of a wave take
@@ -91,8 +92,10 @@ struct LaneRay {  // traversal state of the ray a lane currently owns
 template <int MODE, bool COUNT, int LAYOUT, typename Finish>
 __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                              const float* __restrict__ rays_a, size_t stride, uint32_t n_a, uint32_t* __restrict__ work_counter_a,
-                                             uint32_t* __restrict__ lds, Finish finish, const float* __restrict__ rays_b = nullptr, uint32_t n_b = 0,
-                                             uint32_t* __restrict__ work_counter_b = nullptr) {
+                                             uint32_t* __restrict__ lds, Finish finish, bool any_payload = false,
+                                             const float* __restrict__ rays_b = nullptr, uint32_t n_b = 0, uint32_t* __restrict__ work_counter_b = nullptr) {
+    // any_payload: the any-hit rays come from k_shade's shadow queue, where every ray has the range (kRayTMin, kBackgroundDepth):
+    // the two .w slots of its record carry payload (two contribution channels) instead of tmin / tmax -- 16 bytes less per ray
     const float* __restrict__ rays = rays_a;
     uint32_t n = n_a;
     uint32_t* __restrict__ work_counter = work_counter_a;
@@ -122,6 +125,7 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
     r.best = Hit{0.0f, 0.0f, 0.0f, kMiss};
     r.cur = r.leaf_k = r.index = r.steps = r.cn = r.ct = 0u;
     r.sp = 0;
+    r.pay0 = r.pay1 = 0.0f;
     bool busy = false;
     for (;;) {
         // ---- refill idle lanes from the pool
@@ -157,8 +161,11 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
                 const float4 ro = reinterpret_cast<const float4*>(rays)[idx], rd = reinterpret_cast<const float4*>(rays)[stride + idx];
                 r.o = v3(ro.x, ro.y, ro.z);
                 r.d = v3(rd.x, rd.y, rd.z);
-                r.tmin = ro.w;
-                r.best = Hit{rd.w, 0.0f, 0.0f, kMiss};
+                const bool payload = any_payload && (MODE == 1 || (MODE == 2 && second_pool));
+                r.tmin = payload ? kRayTMin : ro.w;
+                r.best = Hit{payload ? kBackgroundDepth : rd.w, 0.0f, 0.0f, kMiss};
+                r.pay0 = ro.w;
+                r.pay1 = rd.w;
                 r.inv = v3(guarded_inverse(r.d.x), guarded_inverse(r.d.y), guarded_inverse(r.d.z));
                 r.cur = 0u;
                 r.leaf_k = 0u;
@@ -169,7 +176,7 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
                 busy = true;
                 if (MODE == 2) lane_any = second_pool;
                 if (nodes == nullptr) {  // empty scene: everything misses
-                    finish(r.index, r.best, 0u, 0u, MODE == 2 ? lane_any : MODE == 1);
+                    finish(r.index, r.best, 0u, 0u, MODE == 2 ? lane_any : MODE == 1, r.pay0, r.pay1);
                     busy = false;
                 }
             }
@@ -341,7 +348,7 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
         // kMaxSteps bounds the walk so that a corrupt tree can never hang the GPU (a valid tree visits < 2 n nodes)
         if (++r.steps >= kMaxSteps) done = true;
         if (done) {
-            finish(r.index, r.best, r.cn, r.ct, MODE == 2 ? lane_any : MODE == 1);
+            finish(r.index, r.best, r.cn, r.ct, MODE == 2 ? lane_any : MODE == 1, r.pay0, r.pay1);
             busy = false;
         }
     }
@@ -359,7 +366,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(const float4* __restric
     __shared__ uint32_t stack[kLdsStack * kExtendBlock];
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
     unsigned long long tot_n = 0, tot_t = 0;
-    trace_stream<0, COUNT, LAYOUT>(nodes, tris, rays, stride, n, work_counter, stack + threadIdx.x, [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, bool) {
+    trace_stream<0, COUNT, LAYOUT>(nodes, tris, rays, stride, n, work_counter, stack + threadIdx.x, [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, bool, float, float) {
         // one 16-byte record per ray: with persistent waves rays finish out of order, four SoA streams would be four
         // scattered partial-line writes
         reinterpret_cast<float4*>(hits)[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
@@ -390,23 +397,25 @@ __global__ __launch_bounds__(kExtendBlock) void k_shadow(const float4* __restric
     __shared__ uint32_t stack[kLdsStack * kExtendBlock];
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
     unsigned long long tot_n = 0, tot_t = 0;
-    trace_stream<1, COUNT, LAYOUT>(nodes, tris, rays, stride, n, work_counter, stack + threadIdx.x, [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, bool) {
-        if (occluded_out) {
-            occluded_out[i] = h.prim != kMiss ? 1u : 0u;
-        } else if (h.prim == kMiss) {
-            const float4 c = reinterpret_cast<const float4*>(contrib)[i];  // {rgb, path id}
-            uint32_t p = __float_as_uint(c.w);
-            float4* L = reinterpret_cast<float4*>(lacc) + p;  // one 16-byte read-modify-write per path
-            float4 v = *L;
-            *L = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, 0.0f);
-        }
-        if (COUNT) {
-            if (cnt_nodes) cnt_nodes[i] = cn;
-            if (cnt_tris) cnt_tris[i] = ct;
-            tot_n += cn;
-            tot_t += ct;
-        }
-    });
+    trace_stream<1, COUNT, LAYOUT>(
+        nodes, tris, rays, stride, n, work_counter, stack + threadIdx.x,
+        [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, bool, float c_r, float c_g) {
+            if (occluded_out) {
+                occluded_out[i] = h.prim != kMiss ? 1u : 0u;
+            } else if (h.prim == kMiss) {
+                const float2 c = reinterpret_cast<const float2*>(contrib)[i];  // {blue, path id}; red and green rode with the ray
+                float4* L = reinterpret_cast<float4*>(lacc) + __float_as_uint(c.y);  // one 16-byte read-modify-write per path
+                float4 v = *L;
+                *L = make_float4(v.x + c_r, v.y + c_g, v.z + c.x, 0.0f);
+            }
+            if (COUNT) {
+                if (cnt_nodes) cnt_nodes[i] = cn;
+                if (cnt_tris) cnt_tris[i] = ct;
+                tot_n += cn;
+                tot_t += ct;
+            }
+        },
+        occluded_out == nullptr);
     if (COUNT && totals) {
         atomicAdd(&totals[0], tot_n);
         atomicAdd(&totals[1], tot_t);
@@ -429,14 +438,14 @@ __global__ __launch_bounds__(kExtendBlock) void k_trace(const float4* __restrict
     unsigned long long en = 0, et = 0, sn = 0, stt = 0;
     trace_stream<2, COUNT, LAYOUT>(
         nodes, tris, ext_rays, stride, n_ext, work_ext, stack + threadIdx.x,
-        [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, bool any) {
+        [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, bool any, float c_r, float c_g) {
             if (!any) {
                 reinterpret_cast<float4*>(hits)[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
             } else if (h.prim == kMiss) {
-                const float4 c = reinterpret_cast<const float4*>(contrib)[i];  // {rgb, path id}
-                float4* L = reinterpret_cast<float4*>(lacc) + __float_as_uint(c.w);
+                const float2 c = reinterpret_cast<const float2*>(contrib)[i];  // {blue, path id}
+                float4* L = reinterpret_cast<float4*>(lacc) + __float_as_uint(c.y);
                 float4 v = *L;
-                *L = make_float4(v.x + c.x, v.y + c.y, v.z + c.z, 0.0f);
+                *L = make_float4(v.x + c_r, v.y + c_g, v.z + c.x, 0.0f);
             }
             if (COUNT) {
                 en += any ? 0u : cn;
@@ -445,7 +454,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_trace(const float4* __restrict
                 stt += any ? ct : 0u;
             }
         },
-        sh_rays, n_sh, work_sh);
+        true, sh_rays, n_sh, work_sh);
     if (COUNT && totals) {
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             atomicAdd(&totals[0], (unsigned long long)n_ext);
@@ -557,7 +566,6 @@ struct ShadeArgs {
     uint32_t* out_count;
     float* sh_rays;
     float* sh_contrib;
-    uint32_t* sh_pid;
     uint32_t* sh_count;
     float* lacc;             // float4 {r, g, b, -} per path id
     size_t stride;
@@ -746,9 +754,11 @@ __global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
         parity ^= 1u;
         if (emit_shadow) {
             const uint32_t j = slot.sh;
-            reinterpret_cast<float4*>(a.sh_rays)[j] = make_float4(o.x, o.y, o.z, kRayTMin);
-            reinterpret_cast<float4*>(a.sh_rays)[S + j] = make_float4(wl.x, wl.y, wl.z, kBackgroundDepth);
-            reinterpret_cast<float4*>(a.sh_contrib)[j] = make_float4(contrib.x, contrib.y, contrib.z, __uint_as_float(pid));
+            // 40 bytes per shadow ray: its range is always (kRayTMin, kBackgroundDepth), so the .w of the two ray records carry the
+            // red and green contribution; blue and the path id follow in an 8-byte record
+            reinterpret_cast<float4*>(a.sh_rays)[j] = make_float4(o.x, o.y, o.z, contrib.x);
+            reinterpret_cast<float4*>(a.sh_rays)[S + j] = make_float4(wl.x, wl.y, wl.z, contrib.y);
+            reinterpret_cast<float2*>(a.sh_contrib)[j] = make_float2(contrib.z, __uint_as_float(pid));
         }
         if (emit_ext) {
             const uint32_t j = slot.ext;
@@ -1039,7 +1049,7 @@ void launch_shade(hipStream_t st, bool first, const ShadeLaunch& L) {
     a.gbuffer = (const uint4*)L.gbuffer; a.depth = L.depth;
     a.in_rays = L.in_rays; a.in_hits = L.in_hits; a.in_T = L.in_T; a.in_pid = L.in_pid; a.in_count = L.in_count; a.n_first = L.n_first;
     a.out_rays = L.out_rays; a.out_T = L.out_T; a.out_pid = L.out_pid; a.out_count = L.out_count;
-    a.sh_rays = L.sh_rays; a.sh_contrib = L.sh_contrib; a.sh_pid = L.sh_pid; a.sh_count = L.sh_count;
+    a.sh_rays = L.sh_rays; a.sh_contrib = L.sh_contrib; a.sh_count = L.sh_count;
     a.lacc = L.lacc; a.stride = L.stride;
     unsigned grid = grid_for(L.max_n, kShadeBlock, 8192);
     if (first) hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(kShadeBlock), 0, st, a);
