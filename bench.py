@@ -8,9 +8,9 @@ value = Mrays/s = (primary + bounce + shadow rays of all ranks) / max-over-ranks
 Strong scaling: the frame is fixed, tiles are split over the ranks.
 
 Extra objects on the JSON line:
-  roofline     the dominant kernel -- k_extend on one GPU; k_trace (extension queue then shadow queue in one launch, used
-               when the frame is split and launches are short) otherwise: algorithmic bytes (48 + 64 n_nodes + 48 n_tris
-               per ray) / HIP-event time of its launches inside the timed region, against the 8 TB/s HBM3E peak
+  roofline     the dominant kernel -- k_extend (k_trace if --fused-trace 1: extension queue then shadow queue in one
+               launch): algorithmic bytes (48 + 64 n_nodes + 48 n_tris per ray) / HIP-event time of its
+               launches inside the timed region, against the 8 TB/s HBM3E peak
   cpu_baseline the CPU oracle (a port; the reference cannot be built here) path tracing a centred crop of the same
                frame on the host cores; the crop also yields rmse_vs_oracle
 """
@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--node-width", type=int, default=0, help="2 | 4 (0 = library default)")
     ap.add_argument("--node-quant", type=int, default=-1, help="0 | 1 (-1 = library default)")
     ap.add_argument("--refill", type=int, default=-1, help="traversal tuning: idle lanes before a wave refills (RT3_OPT_EXTEND_VARIANT)")
-    ap.add_argument("--fused-trace", type=int, default=-1, help="RT3_OPT_FUSED_TRACE: 1 one k_trace launch per bounce, 0 separate k_shadow / k_extend, -1 library default (by launch size)")
+    ap.add_argument("--fused-trace", type=int, default=-1, help="RT3_OPT_FUSED_TRACE: 1 one k_trace launch per bounce, 0 separate k_shadow / k_extend, -1 library default")
     ap.add_argument("--sah-top", type=int, default=-1, help="RT3_OPT_SAH_TOP: cluster size T of the SAH top (0 = plain LBVH, -1 = library default)")
     ap.add_argument("--pool-chunk", type=int, default=0, help="traversal tuning: rays per pool grab (RT3_OPT_POOL_CHUNK)")
     ap.add_argument("--flags", type=int, default=-1, help="GConst.pad[0] feature flags (-1 = the full estimator); experiments only")

@@ -122,8 +122,7 @@ int rt3_device_name(rt3_ctx *ctx, char *buf, size_t buf_size);
 #define RT3_OPT_NODE_QUANT 7      /* width 4 only: 1 = 64 B nodes with 8-bit conservative child boxes (default), 0 = 128 B fp32 boxes, 2 = compact 48 B nodes (implied references) */
 #define RT3_OPT_WIDE_COLLAPSE 8   /* width 4 only: how binary LBVH nodes are grouped into four-wide nodes: 1 = by surface area (default), 0 = even binary depth */
 #define RT3_OPT_POOL_CHUNK 9      /* traversal tuning: rays a wave takes from the launch's ray pool per grab (default 256) */
-#define RT3_OPT_FUSED_TRACE 10    /* 1: one k_trace launch per bounce for extension + shadow rays; 0: separate k_shadow and k_extend launches;
-                                     -1 (default): fused for batches of at most 96 Mi paths (a frame split over several GPUs), where launches are short */
+#define RT3_OPT_FUSED_TRACE 10    /* 1: one k_trace launch per bounce walks the extension queue and then the shadow queue; 0 (default): separate k_shadow and k_extend launches */
 #define RT3_OPT_SAH_TOP 11       /* T > 0 (default 2): the tree above Karras subtrees of at most T triangles is re-linked by binned SAH on the
                                      host (the reference asks its driver for PREFER_FAST_TRACE builds, raytracing.rs:103,131); 0 = plain GPU LBVH */
 int rt3_set_option(rt3_ctx *ctx, int option, int64_t value);

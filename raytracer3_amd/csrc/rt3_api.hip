@@ -97,7 +97,7 @@ struct rt3_ctx {
     bool opt_profile = false, opt_count = false;
     int opt_variant = 0;  // RT3_OPT_EXTEND_VARIANT: reserved for traversal experiments
     uint32_t opt_leaf_size = 2, opt_node_width = 4, opt_node_quant = 1, opt_collapse = 1, opt_sah_top = 2;
-    int opt_fused_trace = -1;  // -1 auto (by launch size), 0 off, 1 on
+    int opt_fused_trace = 0;  // 1: k_trace (extension + shadow queue in one launch per bounce)
     rt3_stats stats;
     uint64_t primary_rays_pending = 0;
     std::vector<Timed> pending_events;
@@ -463,11 +463,11 @@ int pass_reference_mode(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y,
                 launch_shade(c->stream, bn == 0, L);
             }
             cur ^= 1;
-            // both queues in one launch (k_trace): a launch of the persistent walk ends in a drain -- the waves finish spread over the
-            // time their longest last ray takes (~0.15 ms, measured with per-wave clocks, whatever the chunk size) -- and one launch
-            // per bounce has one drain less than two.  That is +3 % when the frame is split over 8 GPUs (launches of ~2 ms),
-            // +2 % over 4, and nothing on the single-GPU frame (launches > 10 ms), which keeps the separate kernels.
-            const bool fuse = c->opt_fused_trace == 1 || (c->opt_fused_trace < 0 && n_first <= (96u << 20));
+            // both queues in one launch (k_trace, RT3_OPT_FUSED_TRACE = 1): one end-of-launch drain less per bounce (the waves of a
+            // persistent walk finish spread over the time their longest last ray takes, ~0.15 ms), against the cost of mixing the
+            // two ray kinds in a wave.  Which side wins moved with every change of the shadow walk (+3 % at N = 8 before the SAH top,
+            // -3 % after it), so the default is the simple one: separate launches.
+            const bool fuse = c->opt_fused_trace == 1;
             if (nee && bn != B - 1 && fuse) {
                 ScopedTimer t(c, CAT_TRACE);
                 launch_trace(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->rays[cur], c->sh_rays, S, ext_cnt_at(bn), sh_cnt_at(bn), n_first,
@@ -602,7 +602,7 @@ int rt3_set_option(rt3_ctx* c, int option, int64_t value) {
             c->accel_built = false;
             return RT3_OK;
         case RT3_OPT_FUSED_TRACE:
-            if (value < -1 || value > 1) return fail(c, RT3_E_INVALID, "fused trace must be -1 (auto), 0 or 1");
+            if (value < 0 || value > 1) return fail(c, RT3_E_INVALID, "fused trace must be 0 or 1");
             c->opt_fused_trace = (int)value;
             return RT3_OK;
         case RT3_OPT_POOL_CHUNK:
