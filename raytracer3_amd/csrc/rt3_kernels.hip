@@ -2,11 +2,12 @@
 //
 // Pipeline (replaces shaders/old/{gbuffer,refrence_mode,postprocess}.slang + the driver's ray traversal):
 //   k_raygen -> k_extend -> k_gbuffer                                   ("gbuffer" pass)
-//   k_shade<first> -> [k_shadow] -> k_extend -> k_shade -> ... -> k_accumulate   ("refrence_mode" pass)
+//   k_shade<first> -> [k_shadow] -> k_extend -> k_shade -> ... -> k_accumulate   ("refrence_mode" pass; k_trace = k_shadow + k_extend in one launch)
 //   k_postprocess                                                        ("postprocess" pass)
-// All queues are structure-of-arrays of 16-byte records (ray = {o, tmin} + {d, tmax}, state = {T, pdf}, hit = {t, u, v, prim},
-// shadow contribution = {rgb, path id}): lane i touches record i of each stream, 1 KiB per wave instruction, the widest
-// coalesced access; live rays are compacted with __ballot / popcount, one atomic per workgroup.
+// All queues are structure-of-arrays of 16-byte records (ray = {o, tmin} + {d, tmax}, state = {T, pdf}, hit = {t, u, v, prim};
+// shadow ray = {o, contribution.r} + {d, contribution.g} + 8 bytes {contribution.b, path id}): lane i touches record i of each
+// stream, 1 KiB per wave instruction, the widest coalesced access; live rays are compacted with __ballot / popcount, one
+// 64-bit atomic per workgroup for both output queues.
 #include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
@@ -61,12 +62,13 @@ __device__ __forceinline__ void tri_test_nb(float4 q0, float4 q1, float4 q2, V3 
     best.prim = ok ? prim : best.prim;
 }
 
-// Persistent-wave traversal.  Every wave owns a contiguous pool of rays.  One ray per lane; a lane that finishes its ray
-// immediately takes the next one from the pool (refill once >= kRefillLanes lanes are idle), so the wave keeps its 64
-// lanes busy instead of idling until its slowest ray is done: the walk is VALU-issue-bound and a plain one-ray-per-lane
-// loop spent ~49 iterations per 64 rays whose mean length is ~23 steps.
+// Persistent-wave traversal.  The waves of a launch share one pool of rays (chunks of g_pool_chunk, handed out by an atomic
+// cursor).  One ray per lane; a lane that finishes its ray takes the next one from the wave's current chunk (refill once
+// >= g_refill_lanes lanes are idle), so the wave keeps its 64 lanes busy instead of idling until its slowest ray is done: a
+// plain one-ray-per-lane loop spent ~49 iterations per 64 rays whose mean length is ~23 steps.
 //
-// Layouts: kLayoutBinary64 (two fp32 boxes), kLayoutWide128 (four fp32 boxes), kLayoutWide64Q (four 8-bit boxes).
+// Layouts: kLayoutBinary64 (two fp32 boxes), kLayoutWide128 (four fp32 boxes), kLayoutWide64Q (four 8-bit boxes, default),
+// kLayoutWide48Q (the same boxes, implied references).
 // Closest hit: children are visited nearest first, the others are pushed so that they pop in ascending entry distance
 // (order fixed by a 5-comparator network); any hit: farthest first (same network on the negated distance).  No re-cull on pop.  A leaf reference holds 1..8 consecutive triangles.
 // Every step makes exactly ONE memory round trip: a lane first fetches its next item -- the node, or the next
