@@ -446,8 +446,8 @@ int pass_reference_mode(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y,
         uint32_t* pairs = c->d_counters + first;
         uint32_t* pool_cur = c->d_counters + first + 2 * B;  // [b], [B + b]: ray-pool cursors of the k_extend / k_shadow launch of bounce b
         c->pending_counters.push_back(CounterBlock{first, B});
-#define ext_cnt_at(b) (pairs + 2 * (b))
-#define sh_cnt_at(b) (pairs + 2 * (b) + 1)
+        auto ext_cnt_at = [pairs](uint32_t b) { return pairs + 2 * b; };
+        auto sh_cnt_at = [pairs](uint32_t b) { return pairs + 2 * b + 1; };
         int cur = 0;
         for (uint32_t bn = 0; bn < B; bn++) {
             ShadeLaunch L;
