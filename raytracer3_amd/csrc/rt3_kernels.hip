@@ -54,7 +54,10 @@ __device__ __forceinline__ void tri_test_nb(float4 q0, float4 q1, float4 q2, V3 
     float v = dot_fma(d, qv) * inv;
     float t = dot_fma(e2, qv) * inv;
     uint32_t prim = __float_as_uint(q2.y);
-    bool ok = (det != 0.0f) & (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > tmin) &
+    // slightly fat triangles (barycentrics within 2^-20 of an edge count): a ray through a shared edge must not slip between the
+    // two neighbours' roundings (the oracle's tri_test has the rationale and the numbers)
+    constexpr float kEdgeEps = 9.5367431640625e-07f;
+    bool ok = (det != 0.0f) & (u >= -kEdgeEps) & (u <= 1.0f + kEdgeEps) & (v >= -kEdgeEps) & (u + v <= 1.0f + kEdgeEps) & (t > tmin) &
               ((t < best.t) | ((t == best.t) & (prim < best.prim)));
     best.t = ok ? t : best.t;
     best.u = ok ? u : best.u;

@@ -264,9 +264,20 @@ def test_frame_parity_cornell_reference_semantics(cornell):
     assert np.array_equal(light.view(np.uint32), olight.view(np.uint32))
     assert light[..., :3].mean() > 0.01
     assert st.extension_rays == W * H + int(counts[0])
-    # (almost) nothing escapes a closed box: hit points are not offset along the normal (refrence_mode.slang:47) and fp32
-    # Moeller-Trumbore is not watertight, so a few grazing rays near corners leave
+    # (almost) nothing escapes a closed box: hit points are not offset along the normal (refrence_mode.slang:47), so a bounce ray
+    # that starts exactly on a wall and grazes it can still leave
     assert int(counts[0]) >= 0.999 * W * H * 16 * 3
+    # rays aimed exactly at shared edges and vertices do not leak (2^-20 edge tolerance of the triangle test)
+    from test_oracle_bvh import edge_rays
+
+    rays = edge_rays(mesh, [0.0137, 1.0071, 0.3])
+    ctx = Context(0)
+    ctx.upload_mesh(mesh)
+    ctx.build_accel()
+    t, u, v, p, _ = ctx.trace_rays(rays)
+    ot, ou, ov, op = osc.trace_closest(rays)
+    assert (p != L.MISS).all() and np.array_equal(p, op) and np.array_equal(t, ot)
+    ctx.close()
 
 
 def test_frame_parity_textured_cornell():
