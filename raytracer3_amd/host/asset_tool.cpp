@@ -2,7 +2,7 @@
 //
 //   asset_tool glb <scene.glb> <outdir>               dump the flattened Mesh (what `loaded_assets` uploads, world/mod.rs:83-101)
 //   asset_tool exr <sky.exr> <outdir>                 dump the decoded equirect image
-//   asset_tool png <image.png> <outdir>               dump the decoded RGBA8 image
+//   asset_tool png <image.png|.jpg> <outdir>          dump the decoded RGBA8 image (PNG or baseline JPEG)
 //   asset_tool bincode <file> <current|old> <outdir>  dump a processed-asset cache file (assets/mod.rs:118-137)
 //   asset_tool render <scene.glb> <sky.exr|-> <bluenoise.png|-> W H spp bounces flags px py pz dx dy dz fov_deg <out.bin>
 //                                                     load -> upload -> gbuffer / refrence_mode / postprocess on the GPU;
@@ -52,7 +52,7 @@ int main(int argc, char** argv) {
             fclose(f);
         } else if (cmd == "png" && argc == 4) {
             std::vector<uint8_t> raw = A::read_file(argv[2]);
-            A::Image im = A::decode_png(raw.data(), raw.size());
+            A::Image im = A::decode_image(raw.data(), raw.size());
             dump(std::string(argv[3]) + "/image.bin", im.rgba);
             FILE* f = fopen((std::string(argv[3]) + "/manifest.txt").c_str(), "w");
             fprintf(f, "image %u %u\n", im.w, im.h);

@@ -3,15 +3,16 @@
 // Mirrors the reference's loaders (DerEchteKarsten/RayTracer3 `src/assets/mod.rs`):
 //   GltfMeshLoader (:179-200, :207-252)  -> rt3::assets::load_glb      all meshes x primitives, node transforms baked,
 //                                                                       u8/u16/u32 indices, KHR_materials_emissive_strength,
-//                                                                       embedded / external PNG base-colour textures
+//                                                                       embedded / external PNG / baseline-JPEG base-colour textures
 //   Mesh / Material / Vertex (:52-59, :118-133) -> rt3::assets::Mesh   flattened like world/mod.rs:103-125 uploads it
 //   MeshSaver / bincode CONFIG (:135-137, :299-314) -> read_processed_mesh
 //   skybox EXR (main.rs:94, commented)   -> read_exr                    scanline, NONE / ZIPS / ZIP, HALF / FLOAT / UINT
 // and pushes the result through the C ABI (upload()).  Same results as raytracer3_amd/assets.py; tests/test_host_assets.py
-// compares the two loaders array by array.  JPEG and EXR PIZ/PXR24/B44/DWA are not decoded (reported as errors).
+// compares the two loaders array by array.  Progressive JPEG and EXR PIZ/PXR24/B44/DWA are not decoded (reported as errors).
 #pragma once
 #include <zlib.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -201,7 +202,7 @@ inline uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint3
 
 inline Image decode_png(const uint8_t* d, size_t n) {
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
-    if (n < 8 || std::memcmp(d, sig, 8)) throw std::runtime_error("image: not a PNG (JPEG and other formats are not decoded natively)");
+    if (n < 8 || std::memcmp(d, sig, 8)) throw std::runtime_error("image: not a PNG (only PNG and baseline JPEG are decoded natively)");
     uint32_t w = 0, h = 0;
     int depth = 0, ctype = 0, interlace = 0;
     std::vector<uint8_t> idat, plte, trns;
@@ -289,6 +290,249 @@ inline Image decode_png(const uint8_t* d, size_t n) {
         }
     }
     return out;
+}
+
+// ------------------------------------------------------------------------------------------------ baseline JPEG -> RGBA8
+// ITU T.81 baseline sequential DCT, Huffman coded, 8-bit, 1 or 3 components (JFIF YCbCr), sampling factors 1 or 2, restart
+// intervals.  Progressive / arithmetic / 12-bit / CMYK files are reported as unsupported.  Chroma is upsampled by replication
+// (libjpeg's default "fancy" triangle filter differs from this by a few levels along sharp chroma edges).
+class JpegDecoder {
+  public:
+    static Image decode(const uint8_t* d, size_t n) {
+        JpegDecoder j(d, n);
+        return j.run();
+    }
+
+  private:
+    const uint8_t* d_;
+    size_t n_, p_ = 0;
+    struct Huff {
+        uint8_t bits[17] = {0}, vals[256] = {0};
+        int mincode[17], maxcode[18], valptr[17];
+        bool present = false;
+    } dc_[4], ac_[4];
+    uint16_t qt_[4][64] = {{0}};
+    struct Comp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0; std::vector<uint8_t> plane; int pw = 0, ph = 0; } comp_[3];
+    int ncomp_ = 0, width_ = 0, height_ = 0, restart_ = 0;
+    uint32_t bitbuf_ = 0;
+    int bitcnt_ = 0;
+    bool hit_marker_ = false;
+
+    JpegDecoder(const uint8_t* d, size_t n) : d_(d), n_(n) {}
+    [[noreturn]] static void fail(const char* w) { throw std::runtime_error(std::string("JPEG: ") + w); }
+    int u8() { if (p_ >= n_) fail("truncated"); return d_[p_++]; }
+    int u16() { int a = u8(); return (a << 8) | u8(); }
+
+    static void build(Huff& h) {
+        int code = 0, k = 0;
+        for (int l = 1; l <= 16; l++) {
+            h.valptr[l] = k;
+            h.mincode[l] = code;
+            code += h.bits[l];
+            k += h.bits[l];
+            h.maxcode[l] = h.bits[l] ? code - 1 : -1;
+            code <<= 1;
+        }
+        h.maxcode[17] = 0x7FFFFFFF;
+        h.present = true;
+    }
+    int getbit() {
+        if (bitcnt_ == 0) {
+            int b = 0;
+            if (!hit_marker_) {
+                b = p_ < n_ ? d_[p_++] : 0;
+                if (b == 0xFF) {
+                    int b2 = p_ < n_ ? d_[p_] : 0xD9;
+                    if (b2 == 0) p_++;           // stuffed zero
+                    else { hit_marker_ = true; p_--; b = 0; }  // a marker: feed zeros, leave the pointer on it
+                }
+            }
+            bitbuf_ = (uint32_t)b;
+            bitcnt_ = 8;
+        }
+        bitcnt_--;
+        return (int)((bitbuf_ >> bitcnt_) & 1u);
+    }
+    int receive(int s) {
+        int v = 0;
+        for (int i = 0; i < s; i++) v = (v << 1) | getbit();
+        return v;
+    }
+    static int extend(int v, int s) { return s && v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
+    int decode_sym(const Huff& h) {
+        int code = 0;
+        for (int l = 1; l <= 16; l++) {
+            code = (code << 1) | getbit();
+            if (h.maxcode[l] >= 0 && code <= h.maxcode[l] && code >= h.mincode[l]) return h.vals[h.valptr[l] + code - h.mincode[l]];
+        }
+        fail("bad Huffman code");
+    }
+    static void idct8x8(const float* in, uint8_t* out, int stride) {
+        static float c[8][8];
+        static bool init = false;
+        if (!init) {
+            for (int x = 0; x < 8; x++)
+                for (int u = 0; u < 8; u++) c[x][u] = (u == 0 ? 0.35355339059327379f : 0.5f) * std::cos((2 * x + 1) * u * 3.14159265358979323846f / 16.0f);
+            init = true;
+        }
+        float tmp[64];
+        for (int y = 0; y < 8; y++)  // rows
+            for (int x = 0; x < 8; x++) {
+                float s = 0.0f;
+                for (int u = 0; u < 8; u++) s += c[x][u] * in[8 * y + u];
+                tmp[8 * y + x] = s;
+            }
+        for (int x = 0; x < 8; x++)  // columns
+            for (int y = 0; y < 8; y++) {
+                float s = 0.0f;
+                for (int v = 0; v < 8; v++) s += c[y][v] * tmp[8 * v + x];
+                const int q = (int)std::floor(s + 128.5f);
+                out[y * stride + x] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
+            }
+    }
+    void block(Comp& c, int bx, int by) {
+        static const uint8_t zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                                       35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+        float coef[64] = {0};
+        const uint16_t* q = qt_[c.tq];
+        int t = decode_sym(dc_[c.td]);
+        c.pred += extend(receive(t), t);
+        coef[0] = (float)(c.pred * (int)q[0]);
+        for (int k = 1; k < 64;) {
+            const int rs = decode_sym(ac_[c.ta]), r = rs >> 4, s = rs & 15;
+            if (s == 0) {
+                if (r == 15) { k += 16; continue; }
+                break;  // EOB
+            }
+            k += r;
+            if (k > 63) fail("bad AC run");
+            coef[zz[k]] = (float)(extend(receive(s), s) * (int)q[k]);
+            k++;
+        }
+        idct8x8(coef, c.plane.data() + (size_t)(8 * by) * c.pw + 8 * bx, c.pw);
+    }
+    Image run() {
+        if (n_ < 4 || d_[0] != 0xFF || d_[1] != 0xD8) fail("no SOI marker");
+        p_ = 2;
+        bool have_frame = false;
+        for (;;) {
+            int m = u8();
+            if (m != 0xFF) continue;
+            while ((m = u8()) == 0xFF) {}
+            if (m == 0xD9) fail("no scan before EOI");
+            if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+            const int len = u16();
+            const size_t end = p_ + (size_t)len - 2;
+            if (end > n_) fail("truncated segment");
+            if (m == 0xDB) {
+                while (p_ < end) {
+                    const int pq = u8(), t = pq & 15;
+                    if (t > 3) fail("bad quantisation table id");
+                    for (int k = 0; k < 64; k++) qt_[t][k] = (uint16_t)((pq >> 4) ? u16() : u8());  // stored in zig-zag order
+                }
+            } else if (m == 0xC4) {
+                while (p_ < end) {
+                    const int tc = u8(), t = tc & 15;
+                    if (t > 3) fail("bad Huffman table id");
+                    Huff& h = (tc >> 4) ? ac_[t] : dc_[t];
+                    int total = 0;
+                    for (int l = 1; l <= 16; l++) { h.bits[l] = (uint8_t)u8(); total += h.bits[l]; }
+                    if (total > 256) fail("bad Huffman table");
+                    for (int k = 0; k < total; k++) h.vals[k] = (uint8_t)u8();
+                    build(h);
+                }
+            } else if (m == 0xC0 || m == 0xC1) {
+                if (u8() != 8) fail("only 8-bit samples are supported");
+                height_ = u16();
+                width_ = u16();
+                ncomp_ = u8();
+                if ((ncomp_ != 1 && ncomp_ != 3) || !width_ || !height_) fail("only 1- and 3-component images are supported");
+                for (int i = 0; i < ncomp_; i++) {
+                    comp_[i].id = u8();
+                    const int hv = u8();
+                    comp_[i].h = hv >> 4;
+                    comp_[i].v = hv & 15;
+                    comp_[i].tq = u8();
+                    if (comp_[i].h < 1 || comp_[i].h > 2 || comp_[i].v < 1 || comp_[i].v > 2 || comp_[i].tq > 3) fail("unsupported sampling factors");
+                }
+                have_frame = true;
+            } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
+                fail("progressive / lossless / arithmetic-coded JPEG is not supported (baseline only)");
+            } else if (m == 0xDD) {
+                restart_ = u16();
+            } else if (m == 0xDA) {
+                if (!have_frame) fail("scan before frame header");
+                const int ns = u8();
+                if (ns != ncomp_) fail("non-interleaved scans are not supported");
+                for (int i = 0; i < ns; i++) {
+                    const int id = u8(), tt = u8();
+                    int ci = -1;
+                    for (int k = 0; k < ncomp_; k++)
+                        if (comp_[k].id == id) ci = k;
+                    if (ci < 0) fail("scan references an unknown component");
+                    comp_[ci].td = tt >> 4;
+                    comp_[ci].ta = tt & 15;
+                    if (comp_[ci].td > 3 || comp_[ci].ta > 3 || !dc_[comp_[ci].td].present || !ac_[comp_[ci].ta].present) fail("missing Huffman table");
+                }
+                p_ = end;
+                return scan();
+            }
+            p_ = end;
+        }
+    }
+    Image scan() {
+        int hmax = 1, vmax = 1;
+        for (int i = 0; i < ncomp_; i++) { hmax = std::max(hmax, comp_[i].h); vmax = std::max(vmax, comp_[i].v); }
+        if (ncomp_ == 1) { comp_[0].h = comp_[0].v = 1; hmax = vmax = 1; }
+        const int mcux = (width_ + 8 * hmax - 1) / (8 * hmax), mcuy = (height_ + 8 * vmax - 1) / (8 * vmax);
+        for (int i = 0; i < ncomp_; i++) {
+            comp_[i].pw = mcux * comp_[i].h * 8;
+            comp_[i].ph = mcuy * comp_[i].v * 8;
+            comp_[i].plane.assign((size_t)comp_[i].pw * comp_[i].ph, 0);
+            comp_[i].pred = 0;
+        }
+        int left = restart_;
+        for (int my = 0; my < mcuy; my++)
+            for (int mx = 0; mx < mcux; mx++) {
+                if (restart_ && left == 0) {  // RSTn: byte-align, skip the marker, reset the predictors
+                    bitcnt_ = 0;
+                    hit_marker_ = false;
+                    while (p_ + 1 < n_ && !(d_[p_] == 0xFF && d_[p_ + 1] >= 0xD0 && d_[p_ + 1] <= 0xD7)) p_++;
+                    p_ += 2;
+                    for (int i = 0; i < ncomp_; i++) comp_[i].pred = 0;
+                    left = restart_;
+                }
+                for (int i = 0; i < ncomp_; i++)
+                    for (int by = 0; by < comp_[i].v; by++)
+                        for (int bx = 0; bx < comp_[i].h; bx++) block(comp_[i], mx * comp_[i].h + bx, my * comp_[i].v + by);
+                if (restart_) left--;
+            }
+        Image out;
+        out.w = (uint32_t)width_;
+        out.h = (uint32_t)height_;
+        out.rgba.resize((size_t)width_ * height_ * 4);
+        for (int y = 0; y < height_; y++)
+            for (int x = 0; x < width_; x++) {
+                uint8_t* o = out.rgba.data() + 4 * ((size_t)y * width_ + x);
+                auto sample = [&](const Comp& c) -> float { return (float)c.plane[(size_t)(y * c.v / vmax) * c.pw + (x * c.h / hmax)]; };
+                if (ncomp_ == 1) {
+                    o[0] = o[1] = o[2] = (uint8_t)sample(comp_[0]);
+                } else {
+                    const float Y = sample(comp_[0]), cb = sample(comp_[1]) - 128.0f, cr = sample(comp_[2]) - 128.0f;
+                    auto clamp8 = [](float v) -> uint8_t { const int q = (int)std::floor(v + 0.5f); return (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q)); };
+                    o[0] = clamp8(Y + 1.402f * cr);
+                    o[1] = clamp8(Y - 0.344136f * cb - 0.714136f * cr);
+                    o[2] = clamp8(Y + 1.772f * cb);
+                }
+                o[3] = 255;
+            }
+        return out;
+    }
+};
+// PNG or baseline JPEG, by signature
+inline Image decode_image(const uint8_t* d, size_t n) {
+    if (n >= 2 && d[0] == 0xFF && d[1] == 0xD8) return JpegDecoder::decode(d, n);
+    return decode_png(d, n);
 }
 
 // ------------------------------------------------------------------------------------------------ Mesh (assets/mod.rs:118-133, world/mod.rs:103-125)
@@ -475,12 +719,12 @@ class GltfMeshLoader {  // assets/mod.rs:179-200 (`impl AssetLoader`), extension
             const Json& bv = doc_.at("bufferViews").at((size_t)img.at("bufferView").integer(0));
             const size_t off = bv.has("byteOffset") ? (size_t)bv.at("byteOffset").integer(0) : 0, len = (size_t)bv.at("byteLength").integer(0);
             if (off + len > blob_n_) throw std::runtime_error("glTF: image exceeds the binary chunk");
-            return decode_png(blob_ + off, len);
+            return decode_image(blob_ + off, len);
         }
         const size_t slash = path_.find_last_of('/');
         const std::string dir = slash == std::string::npos ? std::string() : path_.substr(0, slash + 1);
         std::vector<uint8_t> raw = read_file(dir + img.at("uri").str);
-        return decode_png(raw.data(), raw.size());
+        return decode_image(raw.data(), raw.size());
     }
 
     void visit(size_t ni, const Mat4& parent) {

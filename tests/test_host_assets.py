@@ -157,6 +157,37 @@ def test_png_decoder_matches_pillow(tool, tmp_path, mode):
     assert np.array_equal(got, np.array(Image.open(p).convert("RGBA"), np.uint8))
 
 
+@pytest.mark.parametrize("mode,subsampling,restart", [("RGB", 0, 0), ("RGB", 2, 0), ("RGB", 1, 0), ("L", 0, 0), ("RGB", 2, 3)])
+def test_jpeg_decoder_tracks_pillow(tool, tmp_path, mode, subsampling, restart):
+    """Baseline JPEG (what glTF scenes ship next to PNG).  Decoders differ legitimately in the IDCT and in chroma upsampling
+    (libjpeg-turbo interpolates, this one replicates), so the comparison has a tolerance: tight for 4:4:4 / grey, loose
+    along chroma edges for 4:2:2 / 4:2:0."""
+    from PIL import Image
+
+    yy, xx = np.mgrid[0:75, 0:101]
+    img = np.stack([127 + 120 * np.sin(xx / 9.0) * np.cos(yy / 13.0), 40 + 2 * xx, 255 - 3 * yy], -1).clip(0, 255).astype(np.uint8)
+    img[20:40, 30:60] = [250, 20, 30]  # a sharp coloured block
+    im = Image.fromarray(img, "RGB").convert(mode)
+    p = tmp_path / "t.jpg"
+    kw = dict(quality=92, subsampling=subsampling)
+    if restart:
+        kw["restart_marker_rows"] = restart
+    try:
+        im.save(p, format="JPEG", **kw)
+    except TypeError:
+        pytest.skip("this Pillow cannot write restart markers")
+    run(tool, "png", p, tmp_path)
+    m = manifest(tmp_path)[0]
+    got = np.fromfile(tmp_path / "image.bin", np.uint8).reshape(int(m[2]), int(m[1]), 4).astype(np.int32)
+    want = np.array(Image.open(p).convert("RGBA"), np.uint8).astype(np.int32)
+    assert got.shape == want.shape and (got[..., 3] == 255).all()
+    diff = np.abs(got[..., :3] - want[..., :3])
+    if subsampling == 0:
+        assert diff.max() <= 3 and diff.mean() < 0.6, (diff.max(), diff.mean())
+    else:
+        assert diff.mean() < 2.5 and np.quantile(diff, 0.99) <= 40, (diff.mean(), np.quantile(diff, 0.99))
+
+
 def test_png_decoder_on_the_reference_bluenoise(tool, tmp_path):
     run(tool, "png", ROOT / "resources" / "bluenoise.png", tmp_path)
     m = manifest(tmp_path)[0]
@@ -228,7 +259,13 @@ def test_loader_errors_are_reported(tool, tmp_path):
     bad.write_bytes(b"glTF" + struct.pack("<II", 1, 12))
     r = subprocess.run([tool, "glb", str(bad), str(tmp_path)], capture_output=True, text=True)
     assert r.returncode == 1 and "not a glTF 2 binary" in r.stderr
-    jpg = tmp_path / "x.png"
-    jpg.write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 32)
-    r = subprocess.run([tool, "png", str(jpg), str(tmp_path)], capture_output=True, text=True)
+    gif = tmp_path / "x.png"
+    gif.write_bytes(b"GIF89a" + b"\0" * 32)
+    r = subprocess.run([tool, "png", str(gif), str(tmp_path)], capture_output=True, text=True)
     assert r.returncode == 1 and "not a PNG" in r.stderr
+    from PIL import Image
+
+    prog = tmp_path / "prog.jpg"
+    Image.fromarray(np.zeros((16, 16, 3), np.uint8), "RGB").save(prog, format="JPEG", progressive=True)
+    r = subprocess.run([tool, "png", str(prog), str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 1 and "progressive" in r.stderr
