@@ -588,3 +588,22 @@ def test_multi_rank_gather_rehearsal(tmp_path):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 3 and d["gather_bit_identical_to_single_rank"] is True and d["value"] > 0
+
+
+def test_lbvh_large_scene_bit_identical():
+    """0.9 M triangles (atrium at 3x tessellation): GPU build (Morton sort, Karras hierarchy, refit, host SAH top, collapse,
+    quantisation) against the oracle's arrays, and 100 k rays with their visit counts."""
+    mesh = scenes.atrium(3.0)
+    assert mesh.n_triangles > 900_000
+    osc = orc.Scene(mesh)
+    ctx = Context(0)
+    ctx.upload_mesh(mesh)
+    ctx.build_accel()
+    assert ctx.accel_info()[:3] == (osc.n_nodes, osc.n_tris, osc.max_depth)
+    nodes, tris = ctx.accel_download()
+    assert np.array_equal(nodes, osc.nodes()) and np.array_equal(tris, osc.tris())
+    rays = rays_random(100_000, 12, [-14, 0.2, -8], [14, 12, 8])
+    t, u, v, p, cn, ct, _ = ctx.trace_rays(rays, counts=True)
+    ot, ou, ov, op, ocn, oct = osc.trace_closest(rays, counts=True, threads=16)
+    assert np.array_equal(p, op) and np.array_equal(t[p != L.MISS], ot[p != L.MISS]) and np.array_equal(cn, ocn) and np.array_equal(ct, oct)
+    ctx.close()
