@@ -578,7 +578,9 @@ struct ShadeArgs {
 
 // refrence_mode.slang:28-57 for one bounce of every live path
 template <bool FIRST>
-__global__ __launch_bounds__(kShadeBlock) void k_shade(ShadeArgs a) {
+// 6 waves per SIMD (80 VGPRs, 32 bytes of scratch): the kernel lives off memory-level parallelism -- 28.8 -> 27.7 ms against the
+// compiler's own choice of 93 VGPRs (4 waves with 512-thread blocks)
+__global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_shade(ShadeArgs a) {
     __shared__ uint32_t append_lds[2][2 * (kShadeBlock / 64 + 1)];  // double-buffered: see block_append2
     uint32_t parity = 0;
     // the marginal sky tables (one guide word + one CDF value per row) are the first two links of every light sample's chain of
