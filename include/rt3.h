@@ -43,6 +43,7 @@ extern "C" {
 #define RT3_FORMAT_R32G32B32A32_SFLOAT 109u /* Light / PrevLight / color (refrence_mode.slang:10-11) */
 #define RT3_FORMAT_R32G32B32A32_UINT 107u   /* packed G-buffer (gbuffer.slang:5) */
 #define RT3_FORMAT_R8G8B8A8_UNORM 37u       /* display image */
+#define RT3_FORMAT_R16_UINT 74u             /* probe ray directions (trace_probes.slang:10, structured_importance_sampling.slang:10) */
 
 /* feature flags carried in GConst.pad[0]; 0 = reference semantics (diffuse BSDF, emissive-only transport,
  * 2 random draws per bounce, refrence_mode.slang:36-57).  The others are north_star additions. */
@@ -50,6 +51,7 @@ extern "C" {
 #define RT3_F_BLUENOISE 2u   /* Cranley-Patterson shift by resources/bluenoise.png */
 #define RT3_F_SPECULAR 4u    /* layered BSDF: DiffuseBrdf under the GGX SpecularBrdf of brdf.slang:141-311 */
 #define RT3_F_FACEFORWARD 8u /* flip the shading normal towards the incoming ray */
+#define RT3_F_PROBE_RADIANCE 16u /* trace_probes: store lerp(prev, radiance, blendfactor) per ray, the store its line 74 keeps in a comment */
 
 /* src/renderer/mod.rs:47-63 == shaders/include/datatypes.slang:28-43.  304 bytes, 16-byte aligned, column-major
  * matrices.  Offsets 0,64,128,192,256,264,268,272,276,280,284,288,296. */
@@ -171,6 +173,13 @@ int rt3_image_unpack_tiles(rt3_ctx *ctx, uint32_t image, uint32_t rank, uint32_t
  *        "gbuffer"       (x,y)=window   bindings {gbuffer RGBA32UI, gbuffer_depth R32F}                (gbuffer.slang:5-6)
  *        "refrence_mode" (x,y)=window   bindings {gbuffer, gbuffer_depth, Light, PrevLight}            (refrence_mode.slang:8-11)
  *        "postprocess"   (x,y,z)=groups of 8x8  bindings {Depth, Out RGBA32F, In RGBA32F}             (postprocess.slang:5-7)
+ *      and the probe-GI passes (restated as written, debug stores included; rules for what the text leaves open are listed in
+ *      DESIGN.md section 11).  A probe owns 16x16 pixels and an 8x8-texel cell of the atlas images; bindings are ordered by
+ *      (descriptor set, binding) as the shaders declare them:
+ *        "structured_importance_sampling" (x,y,1)=probes  {gbuffer, gbuffer_depth, out R16UI, debug R32F, probe_atlas RGBA32F}
+ *        "trace_probes"                   (x,y)=atlas size {gbuffer, gbuffer_depth, directions R16UI, probe_atlas, prev_probe_atlas}
+ *        "spherical_harmonic_conversion"  (x,y,1)=probes  {out buffer of float3x3 (48 B, rows padded to float4), probe_atlas}
+ *        "interpolate_probes"             (x,y,1)=groups of 8x8 over the window  {gbuffer, gbuffer_depth, sh_coeficents buffer, Light}
  *      Work is enqueued on the context's stream and returns immediately. ---- */
 int rt3_pass_launch(rt3_ctx *ctx, const char *pass_name, const char *entry, uint32_t x, uint32_t y, uint32_t z,
                     const void *constants, size_t constants_size, const uint32_t *bindings, uint32_t n_bindings);
@@ -189,7 +198,9 @@ int rt3_trace_rays(rt3_ctx *ctx, const float *rays, uint32_t n, int any_hit, flo
  *      op: 0 hash(u32) 1 zcurve(x,y) 2 murmur3(seed,index) 3 uniform_float(seed,index) 4 gbuffer pack (11 f32 -> 4 u32)
  *      5 gbuffer unpack (4 u32 -> 11 f32) 6 diffuse sample (u0,u1 -> wi) 7 orthonormal basis (n -> b1,b2) 8 AgX (rgb -> rgb)
  *      9 sincos_2pi (u -> sin,cos) 10 atan2 (y,x) 11 rng_seed(px,py,frame)
- *      12 division-free integer helpers (n,d -> n/d, n%d, wrap(int(n), (d & 0xFFFF)+1)).  in/out: host arrays of 32-bit words. ---- */
+ *      12 division-free integer helpers (n,d -> n/d, n%d, wrap(int(n), (d & 0xFFFF)+1))
+ *      13 octa_decode (fx,fy -> n) 14 sh3Evaluate (dir -> 9 coefficients) 15 64-lane bitonic sort (64 keys -> 64 keys, 64 lane ids)
+ *      16 64-lane sum (64 floats -> 1).  in/out: host arrays of 32-bit words. ---- */
 int rt3_selftest_eval(rt3_ctx *ctx, int op, const void *in, uint32_t n, void *out);
 
 int rt3_stats_reset(rt3_ctx *ctx);

@@ -31,6 +31,7 @@ extern "C" {
 #define ORC_F_BLUENOISE 2u
 #define ORC_F_SPECULAR 4u
 #define ORC_F_FACEFORWARD 8u
+#define ORC_F_PROBE_RADIANCE 16u /* trace_probes stores the blended radiance its line 74 keeps in a comment (0: the debug store as written) */
 
 /* src/renderer/mod.rs:47-63 == datatypes.slang:28-43; 304 bytes, column-major matrices */
 typedef struct orc_gconst {
@@ -150,6 +151,23 @@ void orc_pass_reference_mode(const orc_scene *s, const orc_gconst *g, uint32_t x
 /* postprocess.slang:90-112 ; out RGBA32F display-referred */
 void orc_pass_postprocess(const orc_scene *s, const orc_gconst *g, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
                           const float *depth, const float *in, float *out, int n_threads);
+
+/* ---- probe-GI passes (rt3_oracle_probes.c).  probes = 8x8-texel cells of the probe atlas, one per
+ * 16x16 pixel block; atlas images are (8*probes_x) x (8*probes_y); W, H come from g->window_size. ---- */
+void orc_octa_decode(float fx, float fy, float n[3]);           /* packing.slang:77-86 */
+void orc_sh3_evaluate(const float d[3], float sh[9]);           /* spherical_harmonics.slang:30-44, sh[r*3+c] */
+void orc_wave_sort64(float keys[64], uint32_t idx[64]);         /* math.slang:140-160 over the 64 lanes of a wave */
+float orc_wave_sum64(const float v[64]);                        /* WaveActiveSum, fixed butterfly order */
+/* structured_importance_sampling.slang:19-71 : out = R16_UINT atlas, debug = R32F atlas */
+void orc_pass_structured_importance_sampling(const orc_gconst *g, uint32_t probes_x, uint32_t probes_y, const uint32_t *gbuffer,
+                                             uint16_t *out, float *debug);
+/* trace_probes.slang:15-77 : atlas / prev_atlas RGBA32F */
+void orc_pass_trace_probes(const orc_scene *s, const orc_gconst *g, uint32_t probes_x, uint32_t probes_y, const uint32_t *gbuffer,
+                           const float *depth, const uint16_t *directions, const float *prev_atlas, float *atlas, int n_threads);
+/* spherical_harmonic_conversion.slang:9-33 : sh_out[zcurve(3*gx + c, gy)] = 3 rows x float4 (std430 float3x3) */
+void orc_pass_sh_conversion(uint32_t probes_x, uint32_t probes_y, const float *atlas, float *sh_out);
+/* interpolate_probes.slang:11-103 */
+void orc_pass_interpolate_probes(const orc_gconst *g, const uint32_t *gbuffer, const float *depth, const float *sh, float *light);
 
 /* tile map: 64x64 tiles, Z-order over the tile grid, tile i -> rank i % n_ranks.
  * Returns number of pixels owned by `rank`; if out_xy != NULL writes (x,y) pairs in render order. */

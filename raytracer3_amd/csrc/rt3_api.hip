@@ -19,7 +19,7 @@ using namespace rt3;
 
 static_assert(sizeof(rt3_gconst) == 304 && sizeof(GConstDev) == 304, "GConst is 304 bytes (renderer/mod.rs:47-63)");
 static_assert(sizeof(rt3_geometry_info) == 64, "geometry info is 64 bytes");
-static_assert(RT3_F_NEE_SKY == RT3_FLAG_NEE_SKY && RT3_F_BLUENOISE == RT3_FLAG_BLUENOISE && RT3_F_FACEFORWARD == RT3_FLAG_FACEFORWARD && RT3_F_SPECULAR == RT3_FLAG_SPECULAR, "flags");
+static_assert(RT3_F_NEE_SKY == RT3_FLAG_NEE_SKY && RT3_F_BLUENOISE == RT3_FLAG_BLUENOISE && RT3_F_FACEFORWARD == RT3_FLAG_FACEFORWARD && RT3_F_SPECULAR == RT3_FLAG_SPECULAR && RT3_F_PROBE_RADIANCE == RT3_FLAG_PROBE_RADIANCE, "flags");
 
 namespace {
 
@@ -132,6 +132,14 @@ void dev_free(T*& p) {
     p = nullptr;
 }
 
+uint32_t spread1by1(uint32_t x) {  // math.slang:105-112 integer_explode
+    x = (x | (x << 8)) & 0x00FF00FFu;
+    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+uint32_t zcurve_host(uint32_t x, uint32_t y) { return spread1by1(x) | (spread1by1(y) << 1); }  // math.slang:114-117
 uint32_t compact1by1(uint32_t x) {
     x &= 0x55555555u;
     x = (x | (x >> 1)) & 0x33333333u;
@@ -186,6 +194,7 @@ size_t format_bytes(uint32_t f) {
         case RT3_FORMAT_R32G32B32A32_SFLOAT: return 16;
         case RT3_FORMAT_R32G32B32A32_UINT: return 16;
         case RT3_FORMAT_R8G8B8A8_UNORM: return 4;
+        case RT3_FORMAT_R16_UINT: return 2;
         default: return 0;
     }
 }
@@ -513,6 +522,106 @@ int pass_postprocess(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y, ui
     memcpy(&gd, g, sizeof(gd));
     ScopedTimer t(c, CAT_OTHER);
     launch_postprocess(c->stream, gd, scene_dev(c), pl->dev, pl->count, W, (const float*)dp->ptr, in->ptr, out->ptr);
+    HIPC(c, hipGetLastError());
+    return RT3_OK;
+}
+
+// ---- probe-GI passes.  A probe owns a 16x16 pixel block and an 8x8-texel cell of the probe atlas; the passes
+//      run on the whole window on every rank (they are not part of the tile-partitioned path).
+int probe_grid(rt3_ctx* c, const char* pass, uint32_t W, uint32_t H, uint32_t px, uint32_t py) {
+    if (px == 0 || py == 0 || px > W / 16 || py > H / 16)
+        return fail(c, RT3_E_INVALID, std::string(pass) + ": the probe grid must be between 1x1 and floor(W/16) x floor(H/16) probes");
+    return RT3_OK;
+}
+// structured_importance_sampling.slang:7-11 : set 1 {gbuffer, gbuffer_depth, out, debug}, set 2 {probe_atlas}
+int pass_sis(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y, uint32_t z, const uint32_t* b, uint32_t nb) {
+    uint32_t W, H;
+    if (int r = check_window(c, g, &W, &H)) return r;
+    if (z != 1) return fail(c, RT3_E_INVALID, "structured_importance_sampling: dispatch is probes_x x probes_y x 1 groups of 8x8 threads");
+    if (int r = probe_grid(c, "structured_importance_sampling", W, H, x, y)) return r;
+    if (nb != 5) return fail(c, RT3_E_INVALID, "structured_importance_sampling expects 5 bindings {gbuffer, gbuffer_depth, out, debug, probe_atlas}");
+    Resource* gb = image_checked(c, b[0], W, H, RT3_FORMAT_R32G32B32A32_UINT, "gbuffer");
+    Resource* dp = image_checked(c, b[1], W, H, RT3_FORMAT_R32_SFLOAT, "gbuffer_depth");
+    Resource* out = image_checked(c, b[2], x * 8, y * 8, RT3_FORMAT_R16_UINT, "out");
+    Resource* dbg = image_checked(c, b[3], x * 8, y * 8, RT3_FORMAT_R32_SFLOAT, "debug");
+    Resource* at = image_checked(c, b[4], x * 8, y * 8, RT3_FORMAT_R32G32B32A32_SFLOAT, "probe_atlas");
+    if (!gb || !dp || !out || !dbg || !at) return RT3_E_INVALID;
+    ScopedTimer t(c, CAT_OTHER);
+    launch_sis(c->stream, W, x, y, gb->ptr, out->ptr, (float*)dbg->ptr);
+    HIPC(c, hipGetLastError());
+    return RT3_OK;
+}
+// trace_probes.slang:8-12 : set 1 {gbuffer, gbuffer_depth, directions}, set 2 {probe_atlas}, set 3 {prev_probe_atlas}
+int pass_trace_probes(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y, const uint32_t* b, uint32_t nb) {
+    uint32_t W, H;
+    if (int r = check_window(c, g, &W, &H)) return r;
+    if (x % 8 || y % 8) return fail(c, RT3_E_INVALID, "trace_probes: launch size is the probe atlas, 8 x 8 texels per probe");
+    if (int r = probe_grid(c, "trace_probes", W, H, x / 8, y / 8)) return r;
+    if (nb != 5) return fail(c, RT3_E_INVALID, "trace_probes expects 5 bindings {gbuffer, gbuffer_depth, directions, probe_atlas, prev_probe_atlas}");
+    Resource* gb = image_checked(c, b[0], W, H, RT3_FORMAT_R32G32B32A32_UINT, "gbuffer");
+    Resource* dp = image_checked(c, b[1], W, H, RT3_FORMAT_R32_SFLOAT, "gbuffer_depth");
+    Resource* dir = image_checked(c, b[2], x, y, RT3_FORMAT_R16_UINT, "directions");
+    Resource* at = image_checked(c, b[3], x, y, RT3_FORMAT_R32G32B32A32_SFLOAT, "probe_atlas");
+    Resource* pv = image_checked(c, b[4], x, y, RT3_FORMAT_R32G32B32A32_SFLOAT, "prev_probe_atlas");
+    if (!gb || !dp || !dir || !at || !pv) return RT3_E_INVALID;
+    if (at->ptr == pv->ptr) return fail(c, RT3_E_INVALID, "trace_probes: probe_atlas and prev_probe_atlas must be different images");
+    const uint32_t n = x * y;
+    if (int r = ensure_work(c, n, 0)) return r;
+    GConstDev gd;
+    memcpy(&gd, g, sizeof(gd));
+    const size_t S = c->cap;
+    {
+        ScopedTimer t(c, CAT_OTHER);
+        launch_probe_raygen(c->stream, gd, W, x / 8, y / 8, (const float*)dp->ptr, dir->ptr, at->ptr, c->rays[0], S, c->T[0]);
+    }
+    uint32_t wc_slot;
+    if (int r = reserve_counters(c, 1, &wc_slot)) return r;
+    {
+        ScopedTimer t(c, CAT_EXTEND);
+        launch_extend(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->rays[0], S, nullptr, n, n, c->hits, nullptr, nullptr,
+                      c->opt_count ? c->d_totals : nullptr, c->d_counters + wc_slot);
+    }
+    c->primary_rays_pending += n;
+    {
+        ScopedTimer t(c, CAT_OTHER);
+        launch_probe_store(c->stream, scene_dev(c), g->pad[0], g->blendfactor, x / 8, y / 8, c->hits, c->T[0], pv->ptr, at->ptr);
+    }
+    HIPC(c, hipGetLastError());
+    return RT3_OK;
+}
+// spherical_harmonic_conversion.slang:6-7 : set 0 {out}, set 1 {probe_atlas}
+int pass_sh_conversion(rt3_ctx* c, uint32_t x, uint32_t y, uint32_t z, const uint32_t* b, uint32_t nb) {
+    if (z != 1 || x == 0 || y == 0 || x > 8191 || y > 8191)
+        return fail(c, RT3_E_INVALID, "spherical_harmonic_conversion: dispatch is probes_x x probes_y x 1 groups of 8x8 threads");
+    if (nb != 2) return fail(c, RT3_E_INVALID, "spherical_harmonic_conversion expects 2 bindings {out, probe_atlas}");
+    Resource* out = get_res(c, b[0], RT3_TAG_BUFFER);
+    Resource* at = image_checked(c, b[1], x * 8, y * 8, RT3_FORMAT_R32G32B32A32_SFLOAT, "probe_atlas");
+    if (!at) return RT3_E_INVALID;
+    const size_t need = ((size_t)zcurve_host(x * 3 - 1, y - 1) + 1) * 48;  // float3x3 elements at Z-curve indices (:30-32)
+    if (!out || out->bytes < need) return fail(c, RT3_E_INVALID, "spherical_harmonic_conversion: 'out' must be a buffer of at least " + std::to_string(need) + " bytes");
+    ScopedTimer t(c, CAT_OTHER);
+    launch_sh_conversion(c->stream, x, y, at->ptr, out->ptr);
+    HIPC(c, hipGetLastError());
+    return RT3_OK;
+}
+// interpolate_probes.slang:6-9 : set 1 {gbuffer, gbuffer_depth, sh_coeficents}, set 2 {Light}
+int pass_interpolate_probes(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y, uint32_t z, const uint32_t* b, uint32_t nb) {
+    uint32_t W, H;
+    if (int r = check_window(c, g, &W, &H)) return r;
+    if (x != (W + 7) / 8 || y != (H + 7) / 8 || z != 1) return fail(c, RT3_E_INVALID, "interpolate_probes: dispatch must be ceil(W/8) x ceil(H/8) x 1 groups");
+    if (nb != 4) return fail(c, RT3_E_INVALID, "interpolate_probes expects 4 bindings {gbuffer, gbuffer_depth, sh_coeficents, Light}");
+    Resource* gb = image_checked(c, b[0], W, H, RT3_FORMAT_R32G32B32A32_UINT, "gbuffer");
+    Resource* dp = image_checked(c, b[1], W, H, RT3_FORMAT_R32_SFLOAT, "gbuffer_depth");
+    Resource* sh = get_res(c, b[2], RT3_TAG_BUFFER);
+    Resource* li = image_checked(c, b[3], W, H, RT3_FORMAT_R32G32B32A32_SFLOAT, "Light");
+    if (!gb || !dp || !li) return RT3_E_INVALID;
+    const uint32_t npx = W / 16, npy = H / 16;
+    const size_t need = npx && npy ? ((size_t)zcurve_host(npx * 3 - 1, npy - 1) + 1) * 48 : 0;
+    if (!sh || sh->bytes < need) return fail(c, RT3_E_INVALID, "interpolate_probes: 'sh_coeficents' must be a buffer of at least " + std::to_string(need) + " bytes");
+    GConstDev gd;
+    memcpy(&gd, g, sizeof(gd));
+    ScopedTimer t(c, CAT_OTHER);
+    launch_interpolate(c->stream, gd, W, H, gb->ptr, (const float*)dp->ptr, sh->ptr, li->ptr);
     HIPC(c, hipGetLastError());
     return RT3_OK;
 }
@@ -992,7 +1101,13 @@ int rt3_pass_launch(rt3_ctx* c, const char* pass_name, const char* entry, uint32
     if (!strcmp(pass_name, "gbuffer")) return pass_gbuffer(c, &g, x, y, bindings, n_bindings);
     if (!strcmp(pass_name, "refrence_mode")) return pass_reference_mode(c, &g, x, y, bindings, n_bindings);
     if (!strcmp(pass_name, "postprocess")) return pass_postprocess(c, &g, x, y, z, bindings, n_bindings);
-    return fail(c, RT3_E_INVALID, std::string("unknown pass '") + pass_name + "' (known: gbuffer, refrence_mode, postprocess)");
+    if (!strcmp(pass_name, "structured_importance_sampling")) return pass_sis(c, &g, x, y, z, bindings, n_bindings);
+    if (!strcmp(pass_name, "trace_probes")) return pass_trace_probes(c, &g, x, y, bindings, n_bindings);
+    if (!strcmp(pass_name, "spherical_harmonic_conversion")) return pass_sh_conversion(c, x, y, z, bindings, n_bindings);
+    if (!strcmp(pass_name, "interpolate_probes")) return pass_interpolate_probes(c, &g, x, y, z, bindings, n_bindings);
+    return fail(c, RT3_E_INVALID, std::string("unknown pass '") + pass_name +
+                                      "' (known: gbuffer, refrence_mode, postprocess, structured_importance_sampling, trace_probes, "
+                                      "spherical_harmonic_conversion, interpolate_probes)");
 }
 int rt3_frame_wait(rt3_ctx* c) {
     if (!c) return RT3_E_INVALID;

@@ -10,6 +10,7 @@
 #define RT3_FLAG_BLUENOISE 2u
 #define RT3_FLAG_SPECULAR 4u
 #define RT3_FLAG_FACEFORWARD 8u
+#define RT3_FLAG_PROBE_RADIANCE 16u
 
 namespace rt3 {
 
@@ -70,6 +71,16 @@ void launch_postprocess(hipStream_t st, const GConstDev& g, const SceneDev& sc, 
                         const float* depth, const void* in, void* out);
 void launch_pack_tiles(hipStream_t st, const uint32_t* pixels, uint32_t npix, uint32_t width, const void* img, void* dst);
 void launch_unpack_tiles(hipStream_t st, const uint32_t* pixels, uint32_t npix, uint32_t width, const void* src, void* img);
+
+// probe-GI passes (rt3_probes.hip); atlas images are (8 * probes_x) x (8 * probes_y)
+void launch_sis(hipStream_t st, uint32_t W, uint32_t probes_x, uint32_t probes_y, const void* gbuffer, void* out, float* debug);
+void launch_probe_raygen(hipStream_t st, const GConstDev& g, uint32_t W, uint32_t probes_x, uint32_t probes_y, const float* depth, const void* directions,
+                         void* atlas, float* rays, size_t stride, void* d2);
+void launch_probe_store(hipStream_t st, const SceneDev& sc, uint32_t flags, float blend, uint32_t probes_x, uint32_t probes_y, const float* hits,
+                        const void* d2, const void* prev, void* atlas);
+void launch_sh_conversion(hipStream_t st, uint32_t probes_x, uint32_t probes_y, const void* atlas, void* out);
+void launch_interpolate(hipStream_t st, const GConstDev& g, uint32_t W, uint32_t H, const void* gbuffer, const float* depth, const void* sh, void* light);
+void launch_selftest_probes(hipStream_t st, int op, const uint32_t* in, uint32_t n, uint32_t* out);
 
 void set_refill_lanes(uint32_t v);
 void set_pool_chunk(uint32_t v);

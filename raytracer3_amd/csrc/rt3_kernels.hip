@@ -952,13 +952,15 @@ __global__ void k_selftest(int op, const uint32_t* __restrict__ in, uint32_t n, 
     }
 }
 bool selftest_widths(int op, uint32_t* in_w, uint32_t* out_w) {
-    static const uint32_t w[13][2] = {{1, 1}, {2, 1}, {2, 1}, {2, 1}, {11, 4}, {4, 11}, {2, 3}, {3, 6}, {3, 3}, {1, 2}, {2, 1}, {3, 1}, {2, 3}};
-    if (op < 0 || op > 12) return false;
+    static const uint32_t w[17][2] = {{1, 1}, {2, 1}, {2, 1}, {2, 1}, {11, 4}, {4, 11}, {2, 3}, {3, 6}, {3, 3}, {1, 2}, {2, 1}, {3, 1}, {2, 3},
+                                      {2, 3}, {3, 9}, {64, 128}, {64, 1}};
+    if (op < 0 || op > 16) return false;
     *in_w = w[op][0];
     *out_w = w[op][1];
     return true;
 }
 void launch_selftest(hipStream_t st, int op, const uint32_t* in, uint32_t n, uint32_t* out) {
+    if (op >= 13) return launch_selftest_probes(st, op, in, n, out);
     hipLaunchKernelGGL(k_selftest, dim3((n + 255) / 256), dim3(256), 0, st, op, in, n, out);
 }
 

@@ -5,6 +5,8 @@ Per frame, three passes exactly as the old shaders were wired:
   RayTracingPass("gbuffer")        -> packed G-buffer + depth                 shaders/old/gbuffer.slang
   RayTracingPass("refrence_mode")  -> Light (RGBA32F linear radiance)          shaders/old/refrence_mode.slang
   ComputePass("postprocess")       -> display image (AgX)                      shaders/old/postprocess.slang
+and, as a second frame description, the probe-GI chain of the old shaders (`probe_commands`):
+  gbuffer -> structured_importance_sampling -> trace_probes -> spherical_harmonic_conversion -> interpolate_probes
 """
 from __future__ import annotations
 
@@ -91,6 +93,49 @@ class PathTracer:
         self.handles = dict(gbuffer=gbuffer, depth=depth, light=light, prev=prev, color=out)
         return self.handles
 
+    def probe_commands(self, gconst: L.GConst):
+        """The probe-GI frame: one probe per 16x16 pixel block, 8x8 rays per probe in the probe atlas.  Single rank only (the
+        probe passes read the whole G-buffer).  Returns the handles; `Light` receives the interpolated image."""
+        if self.n_ranks != 1:
+            raise ValueError("the probe-GI passes are not tile-partitioned: run them with n_ranks == 1")
+        rg = self.rg
+        rg.begin_frame()
+        W, H = self.window
+        px, py = W // 16, H // 16
+        asize = ImageSize.XY(px * 8, py * 8)
+        gbuffer = rg.image(ImageSize.FullScreen, L.FORMAT_R32G32B32A32_UINT, "gbuffer")
+        depth = rg.image(ImageSize.FullScreen, L.FORMAT_R32_SFLOAT, "gbuffer_depth")
+        light = rg.image(ImageSize.FullScreen, L.FORMAT_R32G32B32A32_SFLOAT, "Light")
+        directions = rg.image(asize, L.FORMAT_R16_UINT, "probe_directions")
+        debug = rg.image(asize, L.FORMAT_R32_SFLOAT, "probe_debug")
+        atlas = rg.image(asize, L.FORMAT_R32G32B32A32_SFLOAT, "probe_atlas")
+        prev_atlas = rg.image(asize, L.FORMAT_R32G32B32A32_SFLOAT, "prev_probe_atlas")
+        sh = rg.buffer(sh_buffer_bytes(px, py), "sh_coeficents")
+        gb = (RayTracingPass.new(rg, "gbuffer").shader("gbuffer").constants(gconst)
+              .write(IMPORTED, gbuffer).write(IMPORTED, depth).launch(WorkSize2D.FullScreen))
+        sis = (ComputePass.new(rg, "structured_importance_sampling").shader("structured_importance_sampling").constants(gconst)
+               .read(gb, gbuffer).read(gb, depth).write(IMPORTED, directions).write(IMPORTED, debug).read(IMPORTED, atlas)
+               .dispatch(DispatchSize.XY(px, py)))
+        tp = (RayTracingPass.new(rg, "trace_probes").shader("trace_probes").constants(gconst)
+              .read(gb, gbuffer).read(gb, depth).read(sis, directions).write(IMPORTED, atlas).read(IMPORTED, prev_atlas)
+              .launch(WorkSize2D.XY(px * 8, py * 8)))
+        shc = (ComputePass.new(rg, "spherical_harmonic_conversion").shader("spherical_harmonic_conversion").constants(gconst)
+               .write(IMPORTED, sh).read(tp, atlas).dispatch(DispatchSize.XY(px, py)))
+        (ComputePass.new(rg, "interpolate_probes").shader("interpolate_probes").constants(gconst)
+         .read(gb, gbuffer).read(gb, depth).read(shc, sh).write(IMPORTED, light).dispatch(DispatchSize.FullScreen))
+        self.handles = dict(gbuffer=gbuffer, depth=depth, light=light, directions=directions, debug=debug, atlas=atlas, prev_atlas=prev_atlas, sh=sh)
+        return self.handles
+
+    def render_probes(self, gconst, wait=True):
+        h = self.probe_commands(gconst)
+        self.rg.draw_frame(h["light"], wait=wait)
+        return h
+
+    def copy_atlas_to_prev(self):
+        """Temporal blend input of trace_probes (prev_probe_atlas, trace_probes.slang:12,74)."""
+        W, H = self.window
+        self.rg.upload(self.handles["prev_atlas"], self.rg.download(self.handles["atlas"], (H // 16 * 8, W // 16 * 8, 4), np.float32))
+
     def render(self, gconst, postprocess=False, wait=True):
         h = self.commands(gconst, postprocess)
         self.rg.draw_frame(h["color"] if postprocess else h["light"], wait=wait)
@@ -158,6 +203,21 @@ class PathTracer:
         if not done:
             return None
         return self.light() if download else True
+
+
+def zcurve(x, y):
+    """ZCurveToLinearIndex (shaders/include/math.slang:105-117)"""
+    def explode(v):
+        v = (v | (v << 8)) & 0x00FF00FF
+        v = (v | (v << 4)) & 0x0F0F0F0F
+        v = (v | (v << 2)) & 0x33333333
+        return (v | (v << 1)) & 0x55555555
+    return explode(x) | (explode(y) << 1)
+
+
+def sh_buffer_bytes(probes_x, probes_y):
+    """Bytes of the float3x3 buffer spherical_harmonic_conversion writes at zcurve(3 * gx + c, gy) (48 B per element)."""
+    return 48 * (zcurve(probes_x * 3 - 1, probes_y - 1) + 1)
 
 
 def gather_tiles(dist, torch, device, rank, n_ranks, counts, pack, unpack, dst=0, finish=None):

@@ -80,10 +80,57 @@ def function_fixture():
     print("functions", (OUT / "functions.npz").stat().st_size // 1024, "KB")
 
 
+def probe_camera():
+    """Cornell camera pulled back so that one column of probes sees the background."""
+    cam = dict(scenes.CORNELL_CAMERA)
+    pos, d = np.array(cam["position"], np.float32), np.array(cam["direction"], np.float32)
+    cam["position"] = tuple(float(x) for x in pos - d * np.float32(2.5))
+    return cam
+
+
+def probe_fixture():
+    """Probe-GI chain on the Cornell box, 96x64 = 6x4 probes: every stage's oracle output."""
+    mesh = scenes.cornell()
+    osc = orc.Scene(mesh)
+    W, H = 96, 64
+    g = orc.camera_gconst(width=W, height=H, **probe_camera())
+    g.frame, g.blendfactor, g.bounces, g.samples = 3, 0.25, 1, 1
+    gb, depth = osc.gbuffer(g)
+    dirs, dbg = orc.structured_importance_sampling(g, gb, W // 16, H // 16)
+    rng = np.random.default_rng(11)
+    prev = rng.uniform(0, 1, (H // 2, W // 2, 4)).astype(np.float32)
+    # hand-made direction words: both mips, colliding targets, two words outside the octahedral map
+    dirs_mixed = dirs.copy()
+    dirs_mixed[8:16, 8:16] = (rng.integers(0, 256, (8, 8)) | 0x8000).astype(np.uint16)
+    dirs_mixed[16:24, 16:24] = rng.integers(0, 64, (8, 8)).astype(np.uint16)
+    dirs_mixed[9, 9], dirs_mixed[17, 18] = 0x8000 | 300, 77
+    atlas = orc.trace_probes(osc, g, gb, depth, dirs, prev)
+    atlas_mixed = orc.trace_probes(osc, g, gb, depth, dirs_mixed, prev)
+    g.pad[0] = orc.F_PROBE_RADIANCE
+    atlas_rad = orc.trace_probes(osc, g, gb, depth, dirs, prev)
+    sh = orc.sh_conversion(atlas_rad)
+    light = orc.interpolate_probes(g, gb, depth, sh)
+    g1 = orc.GConst.from_buffer_copy(bytes(g)); g1.proberng = 1
+    light_rng = orc.interpolate_probes(g1, gb, depth, sh)
+    assert (depth[::16, ::16] == orc.BACKGROUND_DEPTH).any() and (depth[::16, ::16] != orc.BACKGROUND_DEPTH).any()
+    assert (atlas_rad[..., :3] > 0.75 * prev[..., :3] + 0.5).any(), "no probe ray sees the lamp"
+    np.savez_compressed(OUT / "probes.npz", vertices=mesh.vertices, indices=mesh.indices, geometries=mesh.geometries, prim_counts=mesh.prim_counts,
+                        gconst=gbytes(g), gbuffer=gb, depth=depth, directions=dirs, debug=dbg, directions_mixed=dirs_mixed, prev_atlas=prev,
+                        atlas=atlas, atlas_mixed=atlas_mixed, atlas_rad=atlas_rad, sh=sh, light=light, light_rng=light_rng)
+    print("probes", "radiance mean", float(atlas_rad[..., :3].mean()), "light mean", float(light[..., :3].mean()), (OUT / "probes.npz").stat().st_size // 1024, "KB")
+
+
 if __name__ == "__main__":
+    only = set(sys.argv[1:])  # e.g. `gen_golden.py probes` regenerates one fixture; no argument = all
     bn = assets.load_bluenoise()
     FULL = orc.F_NEE_SKY | orc.F_BLUENOISE | orc.F_FACEFORWARD
-    scene_fixture("cornell_ref", scenes.cornell(), None, None, scenes.CORNELL_CAMERA, 64, 64, 4, 4, 0, 2)
-    scene_fixture("atrium_full", scenes.atrium(0.2), scenes.sky(64, 32), bn, scenes.ATRIUM_CAMERA, 64, 36, 4, 4, FULL, 5)
-    scene_fixture("atrium_spec", scenes.atrium(0.2), scenes.sky(64, 32), bn, scenes.ATRIUM_CAMERA, 64, 36, 4, 4, FULL | orc.F_SPECULAR, 6)
-    function_fixture()
+    if not only or "cornell_ref" in only:
+        scene_fixture("cornell_ref", scenes.cornell(), None, None, scenes.CORNELL_CAMERA, 64, 64, 4, 4, 0, 2)
+    if not only or "atrium_full" in only:
+        scene_fixture("atrium_full", scenes.atrium(0.2), scenes.sky(64, 32), bn, scenes.ATRIUM_CAMERA, 64, 36, 4, 4, FULL, 5)
+    if not only or "atrium_spec" in only:
+        scene_fixture("atrium_spec", scenes.atrium(0.2), scenes.sky(64, 32), bn, scenes.ATRIUM_CAMERA, 64, 36, 4, 4, FULL | orc.F_SPECULAR, 6)
+    if not only or "functions" in only:
+        function_fixture()
+    if not only or "probes" in only:
+        probe_fixture()

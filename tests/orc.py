@@ -9,7 +9,7 @@ _lib = None
 
 MISS = 0xFFFFFFFF
 BACKGROUND_DEPTH = 100000.0
-F_NEE_SKY, F_BLUENOISE, F_SPECULAR, F_FACEFORWARD = 1, 2, 4, 8
+F_NEE_SKY, F_BLUENOISE, F_SPECULAR, F_FACEFORWARD, F_PROBE_RADIANCE = 1, 2, 4, 8, 16
 
 
 class GConst(C.Structure):
@@ -66,6 +66,14 @@ def lib():
         L.orc_pass_reference_mode.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, vp, vp, vp, C.c_int]
         L.orc_pass_postprocess.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, vp, C.c_int]
         L.orc_tile_pixels.restype = u32; L.orc_tile_pixels.argtypes = [u32, u32, u32, u32, vp]
+        L.orc_octa_decode.argtypes = [f32, f32, vp]
+        L.orc_sh3_evaluate.argtypes = [vp, vp]
+        L.orc_wave_sort64.argtypes = [vp, vp]
+        L.orc_wave_sum64.restype = f32; L.orc_wave_sum64.argtypes = [vp]
+        L.orc_pass_structured_importance_sampling.argtypes = [vp, u32, u32, vp, vp, vp]
+        L.orc_pass_trace_probes.argtypes = [vp, vp, u32, u32, vp, vp, vp, vp, vp, C.c_int]
+        L.orc_pass_sh_conversion.argtypes = [u32, u32, vp, vp]
+        L.orc_pass_interpolate_probes.argtypes = [vp, vp, vp, vp, vp]
     return _lib
 
 
@@ -190,6 +198,41 @@ class Scene:
         out = np.zeros((H, W, 4), np.float32)
         lib().orc_pass_postprocess(self.h, C.byref(g), x0, y0, x1, y1, ptr(depth), ptr(np.ascontiguousarray(img, np.float32)), ptr(out), threads)
         return out
+
+
+# ---- probe-GI passes (oracle/rt3_oracle_probes.c)
+def sh_buffer_floats(probes_x, probes_y):
+    """floats in a float3x3 buffer indexed by zcurve(3 * gx + c, gy) (12 floats per element)"""
+    return 12 * (lib().orc_zcurve(probes_x * 3 - 1, probes_y - 1) + 1)
+
+
+def structured_importance_sampling(g, gb, probes_x, probes_y):
+    out = np.zeros((probes_y * 8, probes_x * 8), np.uint16); dbg = np.zeros((probes_y * 8, probes_x * 8), np.float32)
+    lib().orc_pass_structured_importance_sampling(C.byref(g), probes_x, probes_y, ptr(np.ascontiguousarray(gb, np.uint32)), ptr(out), ptr(dbg))
+    return out, dbg
+
+
+def trace_probes(scene, g, gb, depth, directions, prev_atlas, threads=8):
+    ah, aw = directions.shape
+    atlas = np.zeros((ah, aw, 4), np.float32)
+    lib().orc_pass_trace_probes(scene.h, C.byref(g), aw // 8, ah // 8, ptr(np.ascontiguousarray(gb, np.uint32)), ptr(np.ascontiguousarray(depth, np.float32)),
+                                ptr(np.ascontiguousarray(directions, np.uint16)), ptr(np.ascontiguousarray(prev_atlas, np.float32)), ptr(atlas), threads)
+    return atlas
+
+
+def sh_conversion(atlas):
+    ah, aw = atlas.shape[:2]
+    out = np.zeros(sh_buffer_floats(aw // 8, ah // 8), np.float32)
+    lib().orc_pass_sh_conversion(aw // 8, ah // 8, ptr(np.ascontiguousarray(atlas, np.float32)), ptr(out))
+    return out
+
+
+def interpolate_probes(g, gb, depth, sh, light_in=None):
+    W, H = int(g.window_size[0]), int(g.window_size[1])
+    light = np.zeros((H, W, 4), np.float32) if light_in is None else np.ascontiguousarray(light_in, np.float32).copy()
+    lib().orc_pass_interpolate_probes(C.byref(g), ptr(np.ascontiguousarray(gb, np.uint32)), ptr(np.ascontiguousarray(depth, np.float32)),
+                                      ptr(np.ascontiguousarray(sh, np.float32)), ptr(light))
+    return light
 
 
 def primary_rays(g, xs, ys, tmin=0.0, tmax=BACKGROUND_DEPTH):
