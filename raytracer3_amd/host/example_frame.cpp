@@ -2,11 +2,15 @@
 // It is the analogue of `renderer::commands` (src/renderer/mod.rs:65-106) for the three path-tracing passes:
 // reads a scene dump, describes one frame with the builder chain, runs it and writes Light (RGBA32F) + colour.
 //
-//   example_frame scene.bin W H spp bounces flags frame out.bin
+//   example_frame scene.bin W H spp bounces flags frame out.bin [probes]
+// With the trailing word `probes` the frame is the probe-GI chain of the old shaders instead (gbuffer ->
+// structured_importance_sampling -> trace_probes -> spherical_harmonic_conversion -> interpolate_probes) and
+// out.bin holds Light followed by the probe atlas.
 // scene.bin: u32 n_verts, n_idx, n_geoms, sky_w, sky_h, bn_w, bn_h, pad | verts (n*8 f32) | indices (u32) |
 //            geometry infos (64 B each) | prim counts (u32) | sky rgb f32 | blue noise rgba8 | camera: pos[3] dir[3] fov aspect (f32)
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "render_graph.hpp"
@@ -19,8 +23,9 @@ static std::vector<T> read_vec(FILE* f, size_t n) {
 }
 
 int main(int argc, char** argv) {
-    if (argc != 9) {
-        fprintf(stderr, "usage: %s scene.bin W H spp bounces flags frame out.bin\n", argv[0]);
+    const bool probes = argc == 10 && std::string(argv[9]) == "probes";
+    if (argc != 9 && !probes) {
+        fprintf(stderr, "usage: %s scene.bin W H spp bounces flags frame out.bin [probes]\n", argv[0]);
         return 2;
     }
     try {
@@ -57,6 +62,47 @@ int main(int argc, char** argv) {
 
         rt3::RenderGraph rg(ctx, W, H);
         rg.begin_frame();
+        if (probes) {
+            const uint32_t px = W / 16, py = H / 16;
+            auto explode = [](uint32_t v) {  // ZCurveToLinearIndex, math.slang:105-117
+                v = (v | (v << 8)) & 0x00FF00FFu;
+                v = (v | (v << 4)) & 0x0F0F0F0Fu;
+                v = (v | (v << 2)) & 0x33333333u;
+                return (v | (v << 1)) & 0x55555555u;
+            };
+            const size_t sh_bytes = 48 * (size_t)((explode(px * 3 - 1) | (explode(py - 1) << 1)) + 1);
+            const auto asize = rt3::ImageSize::XY(px * 8, py * 8);
+            auto gbuffer = rg.image(rt3::ImageSize::FullScreen(), RT3_FORMAT_R32G32B32A32_UINT, "gbuffer");
+            auto depth = rg.image(rt3::ImageSize::FullScreen(), RT3_FORMAT_R32_SFLOAT, "gbuffer_depth");
+            auto light = rg.image(rt3::ImageSize::FullScreen(), RT3_FORMAT_R32G32B32A32_SFLOAT, "Light");
+            auto directions = rg.image(asize, RT3_FORMAT_R16_UINT, "probe_directions");
+            auto debug = rg.image(asize, RT3_FORMAT_R32_SFLOAT, "probe_debug");
+            auto atlas = rg.image(asize, RT3_FORMAT_R32G32B32A32_SFLOAT, "probe_atlas");
+            auto prev_atlas = rg.image(asize, RT3_FORMAT_R32G32B32A32_SFLOAT, "prev_probe_atlas");
+            auto sh = rg.buffer(sh_bytes, "sh_coeficents");
+            auto gb = rt3::RayTracingPass::New(rg, "gbuffer").shader("gbuffer").constants(gconst)
+                          .write(rt3::IMPORTED, gbuffer).write(rt3::IMPORTED, depth).launch(rt3::WorkSize2D::FullScreen());
+            auto sis = rt3::ComputePass::New(rg, "structured_importance_sampling").shader("structured_importance_sampling").constants(gconst)
+                           .read(gb, gbuffer).read(gb, depth).write(rt3::IMPORTED, directions).write(rt3::IMPORTED, debug).read(rt3::IMPORTED, atlas)
+                           .dispatch(rt3::DispatchSize::XY(px, py));
+            auto tp = rt3::RayTracingPass::New(rg, "trace_probes").shader("trace_probes").constants(gconst)
+                          .read(gb, gbuffer).read(gb, depth).read(sis, directions).write(rt3::IMPORTED, atlas).read(rt3::IMPORTED, prev_atlas)
+                          .launch(rt3::WorkSize2D::XY(px * 8, py * 8));
+            auto shc = rt3::ComputePass::New(rg, "spherical_harmonic_conversion").shader("spherical_harmonic_conversion").constants(gconst)
+                           .write(rt3::IMPORTED, sh).read(tp, atlas).dispatch(rt3::DispatchSize::XY(px, py));
+            rt3::ComputePass::New(rg, "interpolate_probes").shader("interpolate_probes").constants(gconst)
+                .read(gb, gbuffer).read(gb, depth).read(shc, sh).write(rt3::IMPORTED, light).dispatch(rt3::DispatchSize::FullScreen());
+            rg.draw_frame(light);
+            std::vector<float> out((size_t)W * H * 4), at((size_t)px * 8 * py * 8 * 4);
+            ctx.check(rt3_resource_download(ctx.raw(), light, out.data(), out.size() * 4), "download");
+            ctx.check(rt3_resource_download(ctx.raw(), atlas, at.data(), at.size() * 4), "download");
+            FILE* o = fopen(argv[8], "wb");
+            fwrite(out.data(), 4, out.size(), o);
+            fwrite(at.data(), 4, at.size(), o);
+            fclose(o);
+            printf("example_frame: probe-GI frame %ux%u, %ux%u probes\n", W, H, px, py);
+            return 0;
+        }
         auto gbuffer = rg.image(rt3::ImageSize::FullScreen(), RT3_FORMAT_R32G32B32A32_UINT, "gbuffer");
         auto depth = rg.image(rt3::ImageSize::FullScreen(), RT3_FORMAT_R32_SFLOAT, "gbuffer_depth");
         auto light = rg.image(rt3::ImageSize::FullScreen(), RT3_FORMAT_R32G32B32A32_SFLOAT, "Light");

@@ -314,3 +314,40 @@ def test_gpu_probe_pass_error_behaviour():
         pt2.probe_commands(cam_g)
     pt2.close()
     pt.close()
+
+
+@gpu
+def test_gpu_cpp_host_renders_the_probe_frame(tmp_path):
+    """The compiled host (raytracer3_amd/host/example_frame.cpp, `probes` mode) describes the same five nodes with the C++
+    builder chain; its Light and probe atlas must equal the oracle chain bit for bit."""
+    import struct
+    import subprocess
+    from raytracer3_amd.renderer import Camera
+    exe = Path(__file__).resolve().parent.parent / "raytracer3_amd" / "host" / "example_frame"
+    if not exe.exists():
+        subprocess.check_call(["make", "-C", str(exe.parent)])
+    mesh = scenes.cornell()
+    W, H, frame = 128, 80, 6
+    cam = Camera(scenes.CORNELL_CAMERA["position"], scenes.CORNELL_CAMERA["direction"], math.radians(scenes.CORNELL_CAMERA["fov_deg"]), W / H)
+    scene = tmp_path / "scene.bin"
+    with open(scene, "wb") as f:
+        f.write(struct.pack("<8I", len(mesh.vertices), len(mesh.indices), len(mesh.geometries), 0, 0, 0, 0, 0))
+        for arr in (mesh.vertices.astype("<f4"), mesh.indices.astype("<u4"), mesh.geometries, mesh.prim_counts.astype("<u4")):
+            f.write(np.ascontiguousarray(arr).tobytes())
+        f.write(np.array([*cam.position, *cam.direction, cam.fov, cam.aspect_ratio], "<f4").tobytes())
+    out = tmp_path / "out.bin"
+    subprocess.check_call([str(exe), str(scene), str(W), str(H), "1", "1", str(L.F_PROBE_RADIANCE), str(frame), str(out), "probes"])
+    data = np.fromfile(out, "<f4")
+    light, atlas = data[:W * H * 4].reshape(H, W, 4), data[W * H * 4:].reshape(H // 16 * 8, W // 16 * 8, 4)
+    g = cam.gconst((W, H))
+    g.samples, g.bounces, g.frame, g.blendfactor = 1, 1, frame, 1.0
+    g.pad[0] = L.F_PROBE_RADIANCE
+    og = orc.GConst.from_buffer_copy(bytes(g))
+    osc = orc.Scene(mesh)
+    ogb, odepth = osc.gbuffer(og)
+    assert (odepth != orc.BACKGROUND_DEPTH).all()  # closed box: every G-buffer texel is written
+    odirs, _ = orc.structured_importance_sampling(og, ogb, W // 16, H // 16)
+    oatlas = orc.trace_probes(osc, og, ogb, odepth, odirs, np.zeros_like(atlas))
+    assert np.array_equal(bits(atlas), bits(oatlas))
+    assert np.array_equal(bits(light), bits(orc.interpolate_probes(og, ogb, odepth, orc.sh_conversion(oatlas))))
+    assert oatlas[..., :3].max() > 1.0  # the lamp is seen
