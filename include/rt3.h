@@ -127,6 +127,7 @@ int rt3_device_name(rt3_ctx *ctx, char *buf, size_t buf_size);
 #define RT3_OPT_FUSED_TRACE 10    /* 1: one k_trace launch per bounce walks the extension queue and then the shadow queue; 0 (default): separate k_shadow and k_extend launches */
 #define RT3_OPT_SAH_TOP 11       /* T > 0 (default 2): the tree above Karras subtrees of at most T triangles is re-linked by binned SAH on the
                                      host (the reference asks its driver for PREFER_FAST_TRACE builds, raytracing.rs:103,131); 0 = plain GPU LBVH */
+#define RT3_OPT_TRACE_BLOCKS 12   /* traversal tuning: persistent workgroups (256 threads) per traversal launch (default 2048 = 8 per CU) */
 int rt3_set_option(rt3_ctx *ctx, int option, int64_t value);
 
 /* ---- scene upload: DynamicBuffer::push (vulkan/buffer.rs:406-420) into the world buffers of

@@ -718,6 +718,10 @@ int rt3_set_option(rt3_ctx* c, int option, int64_t value) {
             if (value < 64 || value > 65536 || (value & 63)) return fail(c, RT3_E_INVALID, "pool chunk must be a multiple of 64 in [64, 65536]");
             set_pool_chunk((uint32_t)value);
             return RT3_OK;
+        case RT3_OPT_TRACE_BLOCKS:
+            if (value < 1 || value > 65535) return fail(c, RT3_E_INVALID, "trace blocks must be in [1, 65535]");
+            set_trace_blocks((uint32_t)value);
+            return RT3_OK;
         case RT3_OPT_WIDE_COLLAPSE:
             if (value != 0 && value != 1) return fail(c, RT3_E_INVALID, "wide collapse must be 0 (even depth) or 1 (surface area)");
             c->opt_collapse = (uint32_t)value;

@@ -84,6 +84,7 @@ void launch_selftest_probes(hipStream_t st, int op, const uint32_t* in, uint32_t
 
 void set_refill_lanes(uint32_t v);
 void set_pool_chunk(uint32_t v);
+void set_trace_blocks(uint32_t v);
 bool selftest_widths(int op, uint32_t* in_w, uint32_t* out_w);
 void launch_selftest(hipStream_t st, int op, const uint32_t* in, uint32_t n, uint32_t* out);
 

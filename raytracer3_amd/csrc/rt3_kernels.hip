@@ -81,6 +81,8 @@ __constant__ uint32_t g_pool_chunk = 256;   // rays per pool grab (RT3_OPT_POOL_
 __constant__ uint32_t g_refill_lanes = 12;  // tuning knob (RT3_OPT_EXTEND_VARIANT)
 void set_refill_lanes(uint32_t v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_refill_lanes), &v, 4); }
 void set_pool_chunk(uint32_t v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pool_chunk), &v, 4); }
+static unsigned g_trace_max_blocks = kExtendMaxBlocks;  // persistent traversal workgroups per launch (RT3_OPT_TRACE_BLOCKS)
+void set_trace_blocks(uint32_t v) { g_trace_max_blocks = v; }
 
 struct LaneRay {  // traversal state of the ray a lane currently owns
     V3 o, d, inv;
@@ -977,7 +979,7 @@ void launch_raygen(hipStream_t st, const GConstDev& g, const uint32_t* pixels, u
 void launch_extend(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float* rays, size_t stride,
                    const uint32_t* count_ptr, uint32_t count_imm, uint32_t max_n, float* hits, uint32_t* cn, uint32_t* ct,
                    unsigned long long* totals, uint32_t* work_counter) {
-    unsigned grid = grid_for(max_n, kExtendBlock, kExtendMaxBlocks);
+    unsigned grid = grid_for(max_n, kExtendBlock, g_trace_max_blocks);
 #define RT3_LAUNCH_EXTEND(C, L)                                                                                                                  \
     hipLaunchKernelGGL((k_extend<C, L>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, hits, cn, ct, totals, \
                        work_counter)
@@ -997,7 +999,7 @@ void launch_extend(hipStream_t st, bool count, int layout, const float4* nodes, 
 void launch_shadow(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float* rays, size_t stride,
                    const uint32_t* count_ptr, uint32_t count_imm, uint32_t max_n, const float* contrib, const uint32_t* pid, float* lacc,
                    size_t lstride, uint32_t* occluded_out, uint32_t* cn, uint32_t* ct, unsigned long long* totals, uint32_t* work_counter) {
-    unsigned grid = grid_for(max_n, kExtendBlock, kExtendMaxBlocks);
+    unsigned grid = grid_for(max_n, kExtendBlock, g_trace_max_blocks);
 #define RT3_LAUNCH_SHADOW(C, L)                                                                                                                \
     hipLaunchKernelGGL((k_shadow<C, L>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, contrib, pid, lacc, \
                        lstride, occluded_out, cn, ct, totals, work_counter)
@@ -1017,7 +1019,7 @@ void launch_shadow(hipStream_t st, bool count, int layout, const float4* nodes, 
 void launch_trace(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float* ext_rays, const float* sh_rays,
                   size_t stride, const uint32_t* ext_count, const uint32_t* sh_count, uint32_t max_n, float* hits, const float* contrib, float* lacc,
                   unsigned long long* totals, uint32_t* work_ext, uint32_t* work_sh) {
-    unsigned grid = grid_for(max_n, kExtendBlock, kExtendMaxBlocks);
+    unsigned grid = grid_for(max_n, kExtendBlock, g_trace_max_blocks);
 #define RT3_LAUNCH_TRACE(C, L)                                                                                                                  \
     hipLaunchKernelGGL((k_trace<C, L>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, ext_rays, sh_rays, stride, ext_count, sh_count, hits, \
                        contrib, lacc, totals, work_ext, work_sh)
