@@ -2,7 +2,7 @@
 # Collect the judged evidence for one round on the GPU box:  tools/profile_round.sh <tag>
 # -> gpurun_out/prof_<tag>/{bench.log, trace/, pmc_fetch/, pmc_write/, pmc_sq/}; summarise with tools/summarize_profile.py
 # (counters are collected in their own passes, never together with --kernel-trace: gpurun refuses such combinations)
-set -o pipefail
+set -e -o pipefail  # a step that fails or is killed at its limit ends the script: no further GPU step after it
 tag=${1:-r}
 out=gpurun_out/prof_$tag
 export TMPDIR=/tmp
