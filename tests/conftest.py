@@ -14,8 +14,8 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # the oracle is test infrastructure: build it on demand (gcc only, a few seconds)
     so = ROOT / "oracle" / "librt3_oracle.so"
-    src = ROOT / "oracle" / "rt3_oracle.c"
-    if not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
+    srcs = [ROOT / "oracle" / n for n in ("rt3_oracle.c", "rt3_oracle_probes.c", "rt3_oracle.h", "Makefile")]
+    if not so.exists() or so.stat().st_mtime < max(p.stat().st_mtime for p in srcs):
         subprocess.check_call(["make", "-C", str(ROOT / "oracle")], stdout=subprocess.DEVNULL)
 
 
