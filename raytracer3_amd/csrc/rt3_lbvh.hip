@@ -16,6 +16,12 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "rt3_device.hpp"
@@ -565,9 +571,8 @@ inline float half_area3(const float* mn, const float* mx) {
 inline float fminh(float a, float b) { return a < b ? a : b; }
 inline float fmaxh(float a, float b) { return a > b ? a : b; }
 // left / right / rcnt: the Karras tree (modified in place); parents are rewritten for every re-linked edge
-bool sah_top_relink(uint32_t nn, std::vector<uint32_t>& left, std::vector<uint32_t>& right, std::vector<uint32_t>& rcnt, std::vector<uint32_t>& pint,
-                    std::vector<uint32_t>& pleaf, const std::vector<float>& lmin, const std::vector<float>& lmax, const std::vector<float>& nbox,
-                    uint32_t T) {
+bool sah_top_relink(uint32_t nn, uint32_t* left, uint32_t* right, uint32_t* rcnt, uint32_t* pint, uint32_t* pleaf, const float* lmin, const float* lmax,
+                    const float* nbox, uint32_t T) {
     std::vector<SahCluster> cl;
     std::vector<uint32_t> pool;
     for (uint32_t i = 0; i < nn; i++) {
@@ -594,97 +599,131 @@ bool sah_top_relink(uint32_t nn, std::vector<uint32_t>& left, std::vector<uint32
     if (nc < 3 || pool.size() != nc - 1) return false;
     std::vector<uint32_t> idx(nc), tmp(nc);
     for (uint32_t i = 0; i < nc; i++) idx[i] = i;
-    struct Job { uint32_t a, n, patch; };
-    std::vector<Job> st;
-    st.push_back(Job{0, nc, 0xFFFFFFFFu});
-    uint32_t next_pool = 0;
+    // A subtree over n clusters takes exactly n - 1 pool nodes, numbered in pre-order: the node of a job is pool[job.pool], its
+    // left subtree (nl clusters) owns pool[job.pool + 1 ..], its right subtree pool[job.pool + nl ..].  Jobs therefore touch disjoint
+    // ranges of idx / tmp / pool and disjoint tree nodes whatever order they run in, which lets the big right subtrees near the
+    // root run on their own threads with a result that does not depend on scheduling.
+    struct Job { uint32_t a, n, pool, patch; };
     const float inf = INFINITY;
-    while (!st.empty()) {
-        const Job j = st.back();
-        st.pop_back();
-        uint32_t ref;
-        if (j.n == 1) {
-            ref = cl[idx[j.a]].ref;
-        } else {
-            const uint32_t node = pool[next_pool++];
-            ref = node;
-            float cmn[3] = {inf, inf, inf}, cmx[3] = {-inf, -inf, -inf};
-            uint32_t total = 0;
+    auto patch_parent = [&](uint32_t patch, uint32_t ref) {
+        if (patch == 0xFFFFFFFFu) return;
+        const uint32_t parent = patch >> 1;
+        if (patch & 1u) right[parent] = ref;
+        else left[parent] = ref;
+        if (ref & 0x80000000u) pleaf[ref & 0x7FFFFFFFu] = parent;
+        else pint[ref] = parent;
+    };
+    // splits one job; returns the number of clusters that go left
+    auto split = [&](const Job& j, uint32_t node) -> uint32_t {
+        float cmn[3] = {inf, inf, inf}, cmx[3] = {-inf, -inf, -inf};
+        uint32_t total = 0;
+        for (uint32_t k = 0; k < j.n; k++) {
+            const SahCluster& c = cl[idx[j.a + k]];
+            total += c.cnt;
+            for (int a = 0; a < 3; a++) {
+                const float ce = (c.mn[a] + c.mx[a]) * 0.5f;
+                cmn[a] = fminh(cmn[a], ce);
+                cmx[a] = fmaxh(cmx[a], ce);
+            }
+        }
+        float best_cost = inf;
+        int best_axis = -1, best_split = 0;
+        for (int a = 0; a < 3; a++) {
+            const float ext = cmx[a] - cmn[a];
+            if (!(ext > 0.0f)) continue;
+            float bmn[16][3], bmx[16][3];
+            uint32_t bc[16];
+            for (int b = 0; b < 16; b++) {
+                bc[b] = 0;
+                for (int q = 0; q < 3; q++) { bmn[b][q] = inf; bmx[b][q] = -inf; }
+            }
             for (uint32_t k = 0; k < j.n; k++) {
                 const SahCluster& c = cl[idx[j.a + k]];
-                total += c.cnt;
-                for (int a = 0; a < 3; a++) {
-                    const float ce = (c.mn[a] + c.mx[a]) * 0.5f;
-                    cmn[a] = fminh(cmn[a], ce);
-                    cmx[a] = fmaxh(cmx[a], ce);
-                }
+                const float ce = (c.mn[a] + c.mx[a]) * 0.5f;
+                int b = (int)(((ce - cmn[a]) / ext) * 16.0f);
+                if (b > 15) b = 15;
+                bc[b] += c.cnt;
+                for (int q = 0; q < 3; q++) { bmn[b][q] = fminh(bmn[b][q], c.mn[q]); bmx[b][q] = fmaxh(bmx[b][q], c.mx[q]); }
             }
-            float best_cost = inf;
-            int best_axis = -1, best_split = 0;
-            for (int a = 0; a < 3; a++) {
-                const float ext = cmx[a] - cmn[a];
-                if (!(ext > 0.0f)) continue;
-                float bmn[16][3], bmx[16][3];
-                uint32_t bc[16];
-                for (int b = 0; b < 16; b++) {
-                    bc[b] = 0;
-                    for (int q = 0; q < 3; q++) { bmn[b][q] = inf; bmx[b][q] = -inf; }
+            float rmn[16][3], rmx[16][3];
+            uint32_t rc[16];
+            for (int b = 15; b >= 0; b--) {
+                for (int q = 0; q < 3; q++) {
+                    rmn[b][q] = b == 15 ? bmn[b][q] : fminh(bmn[b][q], rmn[b + 1][q]);
+                    rmx[b][q] = b == 15 ? bmx[b][q] : fmaxh(bmx[b][q], rmx[b + 1][q]);
                 }
-                for (uint32_t k = 0; k < j.n; k++) {
-                    const SahCluster& c = cl[idx[j.a + k]];
-                    const float ce = (c.mn[a] + c.mx[a]) * 0.5f;
-                    int b = (int)(((ce - cmn[a]) / ext) * 16.0f);
-                    if (b > 15) b = 15;
-                    bc[b] += c.cnt;
-                    for (int q = 0; q < 3; q++) { bmn[b][q] = fminh(bmn[b][q], c.mn[q]); bmx[b][q] = fmaxh(bmx[b][q], c.mx[q]); }
-                }
-                float rmn[16][3], rmx[16][3];
-                uint32_t rc[16];
-                for (int b = 15; b >= 0; b--) {
-                    for (int q = 0; q < 3; q++) {
-                        rmn[b][q] = b == 15 ? bmn[b][q] : fminh(bmn[b][q], rmn[b + 1][q]);
-                        rmx[b][q] = b == 15 ? bmx[b][q] : fmaxh(bmx[b][q], rmx[b + 1][q]);
-                    }
-                    rc[b] = bc[b] + (b == 15 ? 0u : rc[b + 1]);
-                }
-                float lmn[3] = {inf, inf, inf}, lmx[3] = {-inf, -inf, -inf};
-                uint32_t lc = 0;
-                for (int sp = 1; sp < 16; sp++) {
-                    for (int q = 0; q < 3; q++) { lmn[q] = fminh(lmn[q], bmn[sp - 1][q]); lmx[q] = fmaxh(lmx[q], bmx[sp - 1][q]); }
-                    lc += bc[sp - 1];
-                    if (lc == 0 || rc[sp] == 0) continue;
-                    const float cost = half_area3(lmn, lmx) * (float)lc + half_area3(rmn[sp], rmx[sp]) * (float)rc[sp];
-                    if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = sp; }
-                }
+                rc[b] = bc[b] + (b == 15 ? 0u : rc[b + 1]);
             }
-            uint32_t nl = 0;
-            if (best_axis < 0) {
-                nl = j.n / 2;  // coincident centroids: halve in index order
-            } else {           // stable partition by bin
-                const float ext = cmx[best_axis] - cmn[best_axis];
-                uint32_t w = 0, r = 0;
-                for (uint32_t k = 0; k < j.n; k++) {
-                    const SahCluster& c = cl[idx[j.a + k]];
-                    const float ce = (c.mn[best_axis] + c.mx[best_axis]) * 0.5f;
-                    int b = (int)(((ce - cmn[best_axis]) / ext) * 16.0f);
-                    if (b > 15) b = 15;
-                    if (b < best_split) idx[j.a + w++] = idx[j.a + k];
-                    else tmp[r++] = idx[j.a + k];
-                }
-                for (uint32_t k = 0; k < r; k++) idx[j.a + w + k] = tmp[k];
-                nl = w;
+            float lmn[3] = {inf, inf, inf}, lmx[3] = {-inf, -inf, -inf};
+            uint32_t lc = 0;
+            for (int sp = 1; sp < 16; sp++) {
+                for (int q = 0; q < 3; q++) { lmn[q] = fminh(lmn[q], bmn[sp - 1][q]); lmx[q] = fmaxh(lmx[q], bmx[sp - 1][q]); }
+                lc += bc[sp - 1];
+                if (lc == 0 || rc[sp] == 0) continue;
+                const float cost = half_area3(lmn, lmx) * (float)lc + half_area3(rmn[sp], rmx[sp]) * (float)rc[sp];
+                if (cost < best_cost) { best_cost = cost; best_axis = a; best_split = sp; }
             }
-            rcnt[node] = total > T ? total : T + 1u;
-            st.push_back(Job{j.a + nl, j.n - nl, (node << 1) | 1u});  // right first: the left subtree is numbered first (pre-order)
-            st.push_back(Job{j.a, nl, node << 1});
         }
-        if (j.patch != 0xFFFFFFFFu) {
-            const uint32_t parent = j.patch >> 1;
-            if (j.patch & 1u) right[parent] = ref;
-            else left[parent] = ref;
-            if (ref & 0x80000000u) pleaf[ref & 0x7FFFFFFFu] = parent;
-            else pint[ref] = parent;
+        uint32_t nl = 0;
+        if (best_axis < 0) {
+            nl = j.n / 2;  // coincident centroids: halve in index order
+        } else {           // stable partition by bin
+            const float ext = cmx[best_axis] - cmn[best_axis];
+            uint32_t w = 0, r = 0;
+            for (uint32_t k = 0; k < j.n; k++) {
+                const SahCluster& c = cl[idx[j.a + k]];
+                const float ce = (c.mn[best_axis] + c.mx[best_axis]) * 0.5f;
+                int b = (int)(((ce - cmn[best_axis]) / ext) * 16.0f);
+                if (b > 15) b = 15;
+                if (b < best_split) idx[j.a + w++] = idx[j.a + k];
+                else tmp[j.a + r++] = idx[j.a + k];
+            }
+            for (uint32_t k = 0; k < r; k++) idx[j.a + w + k] = tmp[j.a + k];
+            nl = w;
         }
+        rcnt[node] = total > T ? total : T + 1u;
+        return nl;
+    };
+    // one thread's share: an explicit stack; subtrees of at least `fork_min` clusters are handed to `spawn` instead (if given)
+    std::function<void(Job, const std::function<bool(const Job&)>&)> run = [&](Job root, const std::function<bool(const Job&)>& spawn) {
+        std::vector<Job> st;
+        st.push_back(root);
+        while (!st.empty()) {
+            const Job j = st.back();
+            st.pop_back();
+            if (j.n == 1) {
+                patch_parent(j.patch, cl[idx[j.a]].ref);
+                continue;
+            }
+            const uint32_t node = pool[j.pool];
+            const uint32_t nl = split(j, node);
+            patch_parent(j.patch, node);
+            const Job rj{j.a + nl, j.n - nl, j.pool + nl, (node << 1) | 1u}, lj{j.a, nl, j.pool + 1, node << 1};
+            if (!(spawn && spawn(rj))) st.push_back(rj);
+            st.push_back(lj);
+        }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned max_threads = hw > 16 ? 16 : (hw ? hw : 1);
+    const uint32_t fork_min = nc / (4 * max_threads) > 2048 ? nc / (4 * max_threads) : 2048;
+    std::mutex mu;
+    std::vector<std::thread> threads;
+    std::function<bool(const Job&)> spawn = [&](const Job& j) -> bool {
+        if (j.n < fork_min) return false;
+        std::lock_guard<std::mutex> g(mu);
+        if (threads.size() + 1 >= max_threads * 4) return false;  // bounded: at most a few dozen short-lived threads per build
+        threads.emplace_back([&run, &spawn, j] { run(j, spawn); });
+        return true;
+    };
+    run(Job{0, nc, 0, 0xFFFFFFFFu}, max_threads > 1 ? spawn : std::function<bool(const Job&)>());
+    for (size_t t = 0;; t++) {  // threads may still be spawning threads: join until the list stops growing
+        std::thread th;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            if (t >= threads.size()) break;
+            th = std::move(threads[t]);
+        }
+        th.join();
     }
     pint[0] = 0xFFFFFFFFu;
     return true;
@@ -718,6 +757,7 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
     float4* tris_morton = nullptr;  // compact layout: Morton-ordered triangle records before they move into leaf order
     uint64_t *keys_in = nullptr, *keys_out = nullptr;
     void *temp = nullptr, *temp2 = nullptr;
+    char* stage = nullptr;  // pinned host staging of the SAH top
     size_t temp_bytes = 0, temp2_bytes = 0;
     const unsigned grid = (unsigned)(((uint64_t)n + 255) / 256 > 4096 ? 4096 : ((uint64_t)n + 255) / 256);
     uint32_t init_bounds[12];
@@ -781,27 +821,47 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
         hipLaunchKernelGGL(k_refit, dim3(grid), dim3(256), 0, st, left, right, pint, pleaf, lmin, lmax, n, nbox, arrive);
         if (sah_top) {  // re-link the upper tree by SAH on the host, then refit again
             const uint32_t T = sah_top > leaf_max ? sah_top : leaf_max;
-            std::vector<uint32_t> h_left(nn), h_right(nn), h_rcnt(nn), h_pint(nn), h_pleaf(n);
-            std::vector<float> h_lmin((size_t)n * 3), h_lmax((size_t)n * 3), h_nbox((size_t)nn * 6);
+            const bool trace = getenv("RT3_TRACE_BUILD") != nullptr;  // phase times of the host part to stderr
+            auto now = [] { return std::chrono::steady_clock::now(); };
+            auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            const auto t0 = now();
+            // one pinned staging block for the eight arrays: pageable copies made the runtime pin and unpin the user pages around every
+            // transfer, which cost more than the SAH itself (20+ ms of a 40 ms build)
+            const size_t off_left = 0, off_right = off_left + (size_t)nn * 4, off_rcnt = off_right + (size_t)nn * 4, off_pint = off_rcnt + (size_t)nn * 4,
+                         off_pleaf = off_pint + (size_t)nn * 4, off_lmin = off_pleaf + (size_t)n * 4, off_lmax = off_lmin + (size_t)n * 12,
+                         off_nbox = off_lmax + (size_t)n * 12, stage_bytes = off_nbox + (size_t)nn * 24;
+            LB_CHECK(hipHostMalloc((void**)&stage, stage_bytes, hipHostMallocDefault));
+            uint32_t *h_left = (uint32_t*)(stage + off_left), *h_right = (uint32_t*)(stage + off_right), *h_rcnt = (uint32_t*)(stage + off_rcnt),
+                     *h_pint = (uint32_t*)(stage + off_pint), *h_pleaf = (uint32_t*)(stage + off_pleaf);
+            float *h_lmin = (float*)(stage + off_lmin), *h_lmax = (float*)(stage + off_lmax), *h_nbox = (float*)(stage + off_nbox);
+            LB_CHECK(hipMemcpyAsync(h_left, left, (size_t)nn * 4, hipMemcpyDeviceToHost, st));
+            LB_CHECK(hipMemcpyAsync(h_right, right, (size_t)nn * 4, hipMemcpyDeviceToHost, st));
+            LB_CHECK(hipMemcpyAsync(h_rcnt, rcnt, (size_t)nn * 4, hipMemcpyDeviceToHost, st));
+            LB_CHECK(hipMemcpyAsync(h_pint, pint, (size_t)nn * 4, hipMemcpyDeviceToHost, st));
+            LB_CHECK(hipMemcpyAsync(h_pleaf, pleaf, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+            LB_CHECK(hipMemcpyAsync(h_lmin, lmin, (size_t)n * 12, hipMemcpyDeviceToHost, st));
+            LB_CHECK(hipMemcpyAsync(h_lmax, lmax, (size_t)n * 12, hipMemcpyDeviceToHost, st));
+            LB_CHECK(hipMemcpyAsync(h_nbox, nbox, (size_t)nn * 24, hipMemcpyDeviceToHost, st));
             LB_CHECK(hipStreamSynchronize(st));
-            LB_CHECK(hipMemcpy(h_left.data(), left, (size_t)nn * 4, hipMemcpyDeviceToHost));
-            LB_CHECK(hipMemcpy(h_right.data(), right, (size_t)nn * 4, hipMemcpyDeviceToHost));
-            LB_CHECK(hipMemcpy(h_rcnt.data(), rcnt, (size_t)nn * 4, hipMemcpyDeviceToHost));
-            LB_CHECK(hipMemcpy(h_pint.data(), pint, (size_t)nn * 4, hipMemcpyDeviceToHost));
-            LB_CHECK(hipMemcpy(h_pleaf.data(), pleaf, (size_t)n * 4, hipMemcpyDeviceToHost));
-            LB_CHECK(hipMemcpy(h_lmin.data(), lmin, (size_t)n * 12, hipMemcpyDeviceToHost));
-            LB_CHECK(hipMemcpy(h_lmax.data(), lmax, (size_t)n * 12, hipMemcpyDeviceToHost));
-            LB_CHECK(hipMemcpy(h_nbox.data(), nbox, (size_t)nn * 24, hipMemcpyDeviceToHost));
-            if (sah_top_relink(nn, h_left, h_right, h_rcnt, h_pint, h_pleaf, h_lmin, h_lmax, h_nbox, T)) {
-                LB_CHECK(hipMemcpy(left, h_left.data(), (size_t)nn * 4, hipMemcpyHostToDevice));
-                LB_CHECK(hipMemcpy(right, h_right.data(), (size_t)nn * 4, hipMemcpyHostToDevice));
-                LB_CHECK(hipMemcpy(rcnt, h_rcnt.data(), (size_t)nn * 4, hipMemcpyHostToDevice));
-                LB_CHECK(hipMemcpy(pint, h_pint.data(), (size_t)nn * 4, hipMemcpyHostToDevice));
-                LB_CHECK(hipMemcpy(pleaf, h_pleaf.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+            const auto t1 = now();
+            const bool relinked = sah_top_relink(nn, h_left, h_right, h_rcnt, h_pint, h_pleaf, h_lmin, h_lmax, h_nbox, T);
+            const auto t2 = now();
+            if (trace) fprintf(stderr, "rt3 build: host SAH top: download %.2f ms (incl. GPU LBVH drain), relink %.2f ms\n", ms(t0, t1), ms(t1, t2));
+            if (relinked) {
+                LB_CHECK(hipMemcpyAsync(left, h_left, (size_t)nn * 4, hipMemcpyHostToDevice, st));
+                LB_CHECK(hipMemcpyAsync(right, h_right, (size_t)nn * 4, hipMemcpyHostToDevice, st));
+                LB_CHECK(hipMemcpyAsync(rcnt, h_rcnt, (size_t)nn * 4, hipMemcpyHostToDevice, st));
+                LB_CHECK(hipMemcpyAsync(pint, h_pint, (size_t)nn * 4, hipMemcpyHostToDevice, st));
+                LB_CHECK(hipMemcpyAsync(pleaf, h_pleaf, (size_t)n * 4, hipMemcpyHostToDevice, st));
                 LB_CHECK(hipMemsetAsync(arrive, 0, (size_t)nn * 4, st));
                 hipLaunchKernelGGL(k_refit, dim3(grid), dim3(256), 0, st, left, right, pint, pleaf, lmin, lmax, n, nbox, arrive);
+                if (trace) {
+                    LB_CHECK(hipStreamSynchronize(st));
+                    fprintf(stderr, "rt3 build: upload + second refit %.2f ms\n", ms(t2, now()));
+                }
             }
         }
+        const auto t3 = std::chrono::steady_clock::now();
         if (collapse) {
             // top-down, one four-wide level per launch (the frontier of level l+1 is produced by level l); ~log4(n) launches
             uint32_t *fr_a = nullptr, *fr_b = nullptr, *fr_n = nullptr, n_front = 1, wide_levels = 0;
@@ -850,12 +910,15 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
                            quant, collapse, out->nodes, cbase, tbase, tris_morton, out->tris);
         LB_CHECK(hipGetLastError());
         LB_CHECK(hipStreamSynchronize(st));
+        if (getenv("RT3_TRACE_BUILD"))
+            fprintf(stderr, "rt3 build: collapse + emit %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t3).count());
     }
 done:
     for (void* p : {(void*)bmin, (void*)bmax, (void*)lmin, (void*)lmax, (void*)nbox, (void*)bounds, (void*)keys_in, (void*)keys_out, (void*)vals_in,
                     (void*)vals_out, (void*)left, (void*)right, (void*)pint, (void*)pleaf, (void*)arrive, (void*)levels, (void*)rlo, (void*)rcnt,
                     (void*)keep, (void*)newidx, (void*)n_int, (void*)n_ltri, (void*)cbase, (void*)tbase, (void*)tris_morton, temp, temp2})
         (void)hipFree(p);
+    if (stage) (void)hipHostFree(stage);
     if (err != hipSuccess) {
         (void)hipFree(out->nodes);
         (void)hipFree(out->tris);

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Time rt3_accel_build (GPU LBVH + host SAH top + four-wide quantised emit) for the bench scene and a larger one."""
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from raytracer3_amd import _lib as L  # noqa: E402
+from raytracer3_amd import scenes  # noqa: E402
+from raytracer3_amd.render_graph import Context  # noqa: E402
+
+for detail in (1.0, 1.9):
+    mesh = scenes.atrium(detail)
+    ctx = Context(0)
+    ctx.upload_mesh(mesh)
+    for T in (0, 2, 8):
+        ctx.set_option(L.OPT_SAH_TOP, T)
+        ts = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            ctx.build_accel()
+            ts.append(1e3 * (time.perf_counter() - t0))
+        print(f"atrium({detail}): {mesh.n_triangles} triangles, SAH_TOP {T}: build {min(ts[1:]):.1f} ms (first {ts[0]:.1f})", flush=True)
+    ctx.close()
