@@ -6,9 +6,9 @@
 //                                                                       embedded / external PNG / baseline-JPEG base-colour textures
 //   Mesh / Material / Vertex (:52-59, :118-133) -> rt3::assets::Mesh   flattened like world/mod.rs:103-125 uploads it
 //   MeshSaver / bincode CONFIG (:135-137, :299-314) -> read_processed_mesh
-//   skybox EXR (main.rs:94, commented)   -> read_exr                    scanline, NONE / ZIPS / ZIP, HALF / FLOAT / UINT
+//   skybox EXR (main.rs:94, commented)   -> read_exr                    scanline, NONE / RLE / ZIPS / ZIP / PIZ, HALF / FLOAT / UINT
 // and pushes the result through the C ABI (upload()).  Same results as raytracer3_amd/assets.py; tests/test_host_assets.py
-// compares the two loaders array by array.  Progressive JPEG and EXR PIZ/PXR24/B44/DWA are not decoded (reported as errors).
+// compares the two loaders array by array.  Progressive JPEG and EXR PXR24/B44/DWA are not decoded (reported as errors).
 #pragma once
 #include <zlib.h>
 
@@ -864,6 +864,221 @@ inline float half_to_float(uint16_t hbits) {
     std::memcpy(&f, &u, 4);
     return f;
 }
+
+// ---- OpenEXR PIZ: 16-bit range compaction (bitmap + LUT) -> 2-D Haar-like wavelet (ImfWav) -> Huffman with run lengths (ImfHuf),
+//      restated from the published algorithm.  Parity unpinned: no EXR ships with the reference and no other EXR implementation exists in
+//      this image; checked against the independent Python decoder / encoder of raytracer3_amd/assets.py.
+namespace piz {
+constexpr int kEncSize = (1 << 16) + 1, kDecBits = 14, kShortZeroRun = 59, kLongZeroRun = 63, kShortestLongRun = 2 + kLongZeroRun - kShortZeroRun;
+struct BitReader {
+    const uint8_t *p, *e;
+    unsigned __int128 c = 0;  // up to 57 buffered bits + one more byte while a 58-bit code is matched
+    int lc = 0;
+    uint32_t get(int n) {  // MSB first; bytes past the end read as zero
+        while (lc < n) {
+            c = (c << 8) | (p < e ? *p : 0u);
+            ++p;
+            lc += 8;
+        }
+        lc -= n;
+        return (uint32_t)((uint64_t)(c >> lc) & ((1ull << n) - 1ull));
+    }
+};
+inline void canonical(std::vector<uint64_t>& h) {  // in: code lengths; out: length | code << 6 (hufCanonicalCodeTable)
+    uint64_t n[59] = {0};
+    for (uint64_t l : h) n[l]++;
+    uint64_t c = 0;
+    for (int i = 58; i > 0; --i) {
+        const uint64_t nc = (c + n[i]) >> 1;
+        n[i] = c;
+        c = nc;
+    }
+    for (auto& v : h) {
+        const uint64_t l = v;
+        if (l > 0) v = l | (n[l]++ << 6);
+    }
+}
+inline std::vector<uint16_t> huf_uncompress(const uint8_t* comp, size_t n_comp, size_t n_raw) {
+    std::vector<uint16_t> out(n_raw);
+    if (n_raw == 0) return out;
+    if (n_comp < 20) throw std::runtime_error("EXR PIZ: truncated Huffman block");
+    auto u32 = [&](size_t o) { return (uint32_t)comp[o] | ((uint32_t)comp[o + 1] << 8) | ((uint32_t)comp[o + 2] << 16) | ((uint32_t)comp[o + 3] << 24); };
+    const uint32_t im = u32(0), iM = u32(4), table_len = u32(8), n_bits = u32(12);
+    if (im >= (uint32_t)kEncSize || iM >= (uint32_t)kEncSize || 20ull + table_len > n_comp) throw std::runtime_error("EXR PIZ: bad Huffman header");
+    std::vector<uint64_t> h(kEncSize, 0);
+    BitReader tb{comp + 20, comp + 20 + table_len};
+    for (uint32_t s = im; s <= iM;) {  // hufUnpackEncTable
+        const uint32_t l = tb.get(6);
+        if (l == (uint32_t)kLongZeroRun) s += tb.get(8) + kShortestLongRun;
+        else if (l >= (uint32_t)kShortZeroRun) s += l - kShortZeroRun + 2;
+        else h[s++] = l;
+    }
+    canonical(h);
+    struct Dec { uint8_t len = 0; uint32_t lit = 0; std::vector<uint32_t> longs; };
+    std::vector<Dec> dec(1u << kDecBits);
+    for (uint32_t s = im; s <= iM; s++) {  // hufBuildDecTable
+        const uint64_t c = h[s] >> 6;
+        const int l = (int)(h[s] & 63);
+        if (!l) continue;
+        if (c >> l) throw std::runtime_error("EXR PIZ: invalid Huffman table");
+        if (l > kDecBits) dec[c >> (l - kDecBits)].longs.push_back(s);
+        else
+            for (uint64_t k = c << (kDecBits - l), e = k + (1ull << (kDecBits - l)); k < e; k++) {
+                dec[k].len = (uint8_t)l;
+                dec[k].lit = s;
+            }
+    }
+    const uint8_t* data = comp + 20 + table_len;
+    const size_t n_data = std::min<size_t>(n_comp - 20 - table_len, ((size_t)n_bits + 7) / 8);
+    BitReader br{data, data + n_data};
+    size_t produced = 0;
+    while (produced < n_raw) {  // hufDecode
+        while (br.lc < 58) {
+            br.c = (br.c << 8) | (br.p < br.e ? *br.p : 0u);
+            ++br.p;
+            br.lc += 8;
+        }
+        if (br.p > br.e + 32) throw std::runtime_error("EXR PIZ: Huffman data ends early");
+        const Dec& d = dec[(uint32_t)(br.c >> (br.lc - kDecBits)) & ((1u << kDecBits) - 1u)];
+        uint32_t sym = 0;
+        if (d.len) {
+            sym = d.lit;
+            br.lc -= d.len;
+        } else {
+            bool found = false;
+            for (uint32_t cand : d.longs) {
+                const int l = (int)(h[cand] & 63);
+                if (br.lc >= l && ((uint64_t)(br.c >> (br.lc - l)) & ((1ull << l) - 1ull)) == (h[cand] >> 6)) {
+                    sym = cand;
+                    br.lc -= l;
+                    found = true;
+                    break;
+                }
+            }
+            if (!found) throw std::runtime_error("EXR PIZ: invalid Huffman code");
+        }
+        if (sym == iM) {  // run-length symbol: repeat the previous value
+            const uint32_t run = br.get(8);
+            if (produced == 0 || produced + run > n_raw) throw std::runtime_error("EXR PIZ: bad run length");
+            for (uint32_t k = 0; k < run; k++, produced++) out[produced] = out[produced - 1];
+        } else {
+            out[produced++] = (uint16_t)sym;
+        }
+    }
+    return out;
+}
+inline void wdec14(uint16_t l, uint16_t h, uint16_t& a, uint16_t& b) {
+    const int ls = (int16_t)l, hs = (int16_t)h, ai = ls + (hs & 1) + (hs >> 1);
+    a = (uint16_t)(int16_t)ai;
+    b = (uint16_t)(int16_t)(ai - hs);
+}
+inline void wdec16(uint16_t l, uint16_t h, uint16_t& a, uint16_t& b) {
+    const int m = l, d = h, bb = (m - (d >> 1)) & 0xFFFF, aa = (d + bb - 0x8000) & 0xFFFF;
+    b = (uint16_t)bb;
+    a = (uint16_t)aa;
+}
+inline void wav2_decode(uint16_t* in, int nx, int ox, int ny, int oy, uint16_t mx) {  // ImfWav wav2Decode
+    const bool w14 = mx < (1 << 14);
+    const int n = nx > ny ? ny : nx;
+    int p = 1, p2;
+    while (p <= n) p <<= 1;
+    p >>= 1;
+    p2 = p;
+    p >>= 1;
+    auto dec = [&](uint16_t l, uint16_t h, uint16_t& a, uint16_t& b) { w14 ? wdec14(l, h, a, b) : wdec16(l, h, a, b); };
+    while (p >= 1) {
+        uint16_t* py = in;
+        uint16_t* ey = in + (ptrdiff_t)oy * (ny - p2);
+        const ptrdiff_t oy1 = (ptrdiff_t)oy * p, oy2 = (ptrdiff_t)oy * p2, ox1 = (ptrdiff_t)ox * p, ox2 = (ptrdiff_t)ox * p2;
+        uint16_t i00, i01, i10, i11;
+        for (; py <= ey; py += oy2) {
+            uint16_t* px = py;
+            uint16_t* ex = py + (ptrdiff_t)ox * (nx - p2);
+            for (; px <= ex; px += ox2) {
+                uint16_t *p01 = px + ox1, *p10 = px + oy1, *p11 = p10 + ox1;
+                dec(*px, *p10, i00, i10);
+                dec(*p01, *p11, i01, i11);
+                dec(i00, i01, *px, *p01);
+                dec(i10, i11, *p10, *p11);
+            }
+            if (nx & p) {
+                uint16_t* p10 = px + oy1;
+                dec(*px, *p10, i00, *p10);
+                *px = i00;
+            }
+        }
+        if (ny & p) {
+            uint16_t* px = py;
+            uint16_t* ex = py + (ptrdiff_t)ox * (nx - p2);
+            for (; px <= ex; px += ox2) {
+                uint16_t* p01 = px + ox1;
+                dec(*px, *p01, i00, *p01);
+                *px = i00;
+            }
+        }
+        p2 = p;
+        p >>= 1;
+    }
+}
+// block -> uncompressed scanline block; sizes[c] = 16-bit words per sample of channel c (1 HALF, 2 FLOAT / UINT)
+inline std::vector<uint8_t> unpack(const uint8_t* comp, size_t n_comp, const std::vector<int>& sizes, uint32_t w, uint32_t n_lines) {
+    size_t total = 0;
+    for (int sz : sizes) total += (size_t)sz * w * n_lines;
+    if (n_comp < 8) throw std::runtime_error("EXR PIZ: truncated block");
+    const uint32_t lo = comp[0] | (comp[1] << 8), hi = comp[2] | (comp[3] << 8);
+    std::vector<uint8_t> bitmap(8192, 0);
+    size_t p = 4;
+    if (lo <= hi) {
+        if (hi >= 8192 || p + (hi - lo + 1) + 4 > n_comp) throw std::runtime_error("EXR PIZ: bad bitmap range");
+        std::memcpy(&bitmap[lo], comp + p, hi - lo + 1);
+        p += hi - lo + 1;
+    }
+    const int32_t length = (int32_t)((uint32_t)comp[p] | ((uint32_t)comp[p + 1] << 8) | ((uint32_t)comp[p + 2] << 16) | ((uint32_t)comp[p + 3] << 24));
+    p += 4;
+    if (length < 0 || p + (size_t)length > n_comp) throw std::runtime_error("EXR PIZ: bad Huffman length");
+    std::vector<uint16_t> lut(65536, 0);
+    uint32_t k = 0;
+    for (uint32_t i = 0; i < 65536; i++)
+        if (i == 0 || (bitmap[i >> 3] & (1u << (i & 7)))) lut[k++] = (uint16_t)i;
+    const uint16_t mx = (uint16_t)(k - 1);
+    std::vector<uint16_t> buf = huf_uncompress(comp + p, (size_t)length, total);
+    std::vector<size_t> start(sizes.size());
+    size_t o = 0;
+    for (size_t c = 0; c < sizes.size(); c++) {
+        start[c] = o;
+        for (int j = 0; j < sizes[c]; j++) wav2_decode(buf.data() + o + j, (int)w, sizes[c], (int)n_lines, (int)w * sizes[c], mx);
+        o += (size_t)sizes[c] * w * n_lines;
+    }
+    for (auto& v : buf) v = lut[v];
+    std::vector<uint8_t> out(total * 2);
+    size_t q = 0;
+    for (uint32_t y = 0; y < n_lines; y++)
+        for (size_t c = 0; c < sizes.size(); c++) {
+            const uint16_t* row = buf.data() + start[c] + (size_t)y * w * sizes[c];
+            for (size_t i = 0; i < (size_t)w * sizes[c]; i++) {
+                out[q++] = (uint8_t)(row[i] & 0xFF);
+                out[q++] = (uint8_t)(row[i] >> 8);
+            }
+        }
+    return out;
+}
+}  // namespace piz
+inline std::vector<uint8_t> exr_rle_expand(const uint8_t* in, size_t n, size_t want) {  // ImfRle rleUncompress
+    std::vector<uint8_t> out;
+    out.reserve(want);
+    for (size_t p = 0; p < n;) {
+        const int c = (int8_t)in[p++];
+        if (c < 0) {
+            if (p + (size_t)(-c) > n) throw std::runtime_error("EXR RLE: truncated block");
+            out.insert(out.end(), in + p, in + p + (-c));
+            p += (size_t)(-c);
+        } else {
+            if (p >= n) throw std::runtime_error("EXR RLE: truncated block");
+            out.insert(out.end(), (size_t)c + 1, in[p++]);
+        }
+    }
+    return out;
+}
 inline SkyImage read_exr(const std::string& path) {
     std::vector<uint8_t> d = read_file(path);
     auto le32 = [&](size_t p) -> uint32_t {
@@ -889,9 +1104,9 @@ inline SkyImage read_exr(const std::string& path) {
     for (const char* need : {"compression", "channels", "dataWindow"})
         if (!attrs.count(need)) throw std::runtime_error(path + ": EXR header lacks '" + need + "'");
     const int comp = d[attrs["compression"].first];
-    if (comp != 0 && comp != 2 && comp != 3)
-        throw std::runtime_error(path + ": EXR compression " + std::to_string(comp) + " is not supported (uncompressed, ZIPS and ZIP are; PIZ / PXR24 / B44 / DWA are not)");
-    const uint32_t lines_per_block = comp == 3 ? 16u : 1u;
+    if (comp < 0 || comp > 4)
+        throw std::runtime_error(path + ": EXR compression " + std::to_string(comp) + " is not supported (uncompressed, RLE, ZIPS, ZIP and PIZ are; PXR24 / B44 / DWA are not)");
+    const uint32_t lines_per_block = comp == 3 ? 16u : (comp == 4 ? 32u : 1u);
     struct Chan { std::string name; int type; };
     std::vector<Chan> chans;
     for (size_t q = attrs["channels"].first; d[q] != 0;) {
@@ -917,9 +1132,13 @@ inline SkyImage read_exr(const std::string& path) {
         if (o + 8 + size > d.size()) throw std::runtime_error(path + ": EXR block exceeds the file");
         std::vector<uint8_t> block(d.begin() + (long)(o + 8), d.begin() + (long)(o + 8 + size));
         const size_t want = line_bytes * n_lines;
-        if (comp && size < want) {  // deflate -> undo the delta predictor -> re-interleave the two byte halves
-            std::vector<uint8_t> t = inflate_all(block.data(), block.size(), want);
-            if (t.size() != want) throw std::runtime_error(path + ": EXR ZIP block has the wrong size");
+        if (comp == 4 && size < want) {  // a block that does not shrink is stored raw
+            std::vector<int> sizes;
+            for (auto& c : chans) sizes.push_back(c.type == 1 ? 1 : 2);
+            block = piz::unpack(block.data(), block.size(), sizes, img.w, n_lines);
+        } else if (comp && size < want) {  // deflate / RLE -> undo the delta predictor -> re-interleave the two byte halves
+            std::vector<uint8_t> t = comp == 1 ? exr_rle_expand(block.data(), block.size(), want) : inflate_all(block.data(), block.size(), want);
+            if (t.size() != want) throw std::runtime_error(path + ": EXR ZIP / RLE block has the wrong size");
             for (size_t k = 1; k < want; k++) t[k] = (uint8_t)(t[k - 1] + t[k] - 128);
             block.resize(want);
             const size_t half = (want + 1) / 2;

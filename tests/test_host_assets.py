@@ -195,17 +195,65 @@ def test_png_decoder_on_the_reference_bluenoise(tool, tmp_path):
     assert np.array_equal(got, assets.load_bluenoise())
 
 
-@pytest.mark.parametrize("compression", ["none", "zips", "zip"])
-def test_exr_reader_matches_python(tool, tmp_path, compression):
+@pytest.mark.parametrize("half", [False, True])
+@pytest.mark.parametrize("compression", ["none", "rle", "zips", "zip", "piz"])
+def test_exr_reader_matches_python(tool, tmp_path, compression, half):
+    """Every scanline compression the loaders read, FLOAT and HALF pixels; 96x40 = a full 32-line PIZ block plus a ragged one.
+    RLE and PIZ files come from the encoders of raytracer3_amd/assets.py (no other EXR writer exists here: parity unpinned)."""
     sky = scenes.sky(96, 40).astype(np.float32)
     sky[3, 5] = [5e4, 4e4, 3e4]
     p = tmp_path / "sky.exr"
-    assets.write_exr(p, sky, compression)
+    assets.write_exr(p, sky, compression, half=half)
+    want = np.ascontiguousarray(sky.astype(np.float16).astype(np.float32) if half else sky)
     run(tool, "exr", p, tmp_path)
     m = manifest(tmp_path)[0]
     got = np.fromfile(tmp_path / "sky.bin", np.float32).reshape(int(m[2]), int(m[1]), 3)
-    assert np.array_equal(got.view(np.uint32), sky.view(np.uint32))
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     assert np.array_equal(got.view(np.uint32), assets.read_exr(p).view(np.uint32))
+
+
+@pytest.mark.parametrize("shape", [(1, 1), (1, 9), (9, 1), (33, 17), (70, 129), (64, 64)])
+def test_exr_piz_and_rle_odd_sizes(tool, tmp_path, shape):
+    """Wavelet corner cases (odd rows / columns at every level, images smaller than a block), noise (every 16-bit value in
+    use: the 16-bit wavelet path and long Huffman codes), flat areas (run-length symbol) and FLOAT pixels (two planes per channel)."""
+    h, w = shape
+    rng = np.random.default_rng(h * 131 + w)
+    img = rng.uniform(-3, 3, (h, w, 3)).astype(np.float32)
+    img[: h // 2, : w // 2] = 0.5
+    if h * w > 2000:
+        img[h // 2 :, :, 0] = rng.integers(0, 65536, (h - h // 2, w)).astype(np.uint16).view(np.float16).astype(np.float32)  # all half bit patterns
+    img = np.nan_to_num(img, nan=1.0, posinf=6e4, neginf=-6e4)
+    for compression, half in (("piz", True), ("piz", False), ("rle", True), ("rle", False)):
+        p = tmp_path / f"{compression}{int(half)}.exr"
+        assets.write_exr(p, img, compression, half=half)
+        want = np.ascontiguousarray(img.astype(np.float16).astype(np.float32) if half else img)
+        back = assets.read_exr(p)
+        assert np.array_equal(back.view(np.uint32), want.view(np.uint32)), (compression, half)
+        run(tool, "exr", p, tmp_path)
+        got = np.fromfile(tmp_path / "sky.bin", np.float32).reshape(h, w, 3)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (compression, half, "native")
+
+
+def test_exr_piz_building_blocks():
+    """The published pieces on their own: canonical Huffman codes form a prefix code with the longest codes numerically first, the
+    wavelet is exactly invertible in both its 14-bit and 16-bit forms, a run of equal values costs one code + the run symbol + 8 bits."""
+    from raytracer3_amd.assets import _huf_canonical, _huf_compress, _huf_uncompress, _wav2
+    lengths = [2, 2, 3, 3, 3, 4, 4, 0, 0]
+    codes = _huf_canonical(lengths)
+    words = [format(c, f"0{l}b") for c, l in zip(codes, lengths) if l]
+    assert all(not b.startswith(a) for a in words for b in words if a != b)
+    assert codes[5] == 0 and codes[6] == 1  # the 4-bit codes start at 0
+    rng = np.random.default_rng(2)
+    for mx in (5, (1 << 14) - 1, 1 << 14, 65535):
+        a = rng.integers(0, mx + 1, (19, 23)).astype(np.uint16)
+        b = a.copy()
+        _wav2(b, mx, False)
+        assert not np.array_equal(a, b)
+        _wav2(b, mx, True)
+        assert np.array_equal(a, b)
+    raw = np.array([7] * 200 + [9], np.uint16)
+    comp = _huf_compress(raw)
+    assert len(comp) < 20 + 16 + 8 and np.array_equal(_huf_uncompress(comp, len(raw)), raw)
 
 
 def test_exr_half_channels(tool, tmp_path):
