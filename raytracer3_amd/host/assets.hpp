@@ -8,7 +8,7 @@
 //   MeshSaver / bincode CONFIG (:135-137, :299-314) -> read_processed_mesh
 //   skybox EXR (main.rs:94, commented)   -> read_exr                    scanline, NONE / RLE / ZIPS / ZIP / PIZ, HALF / FLOAT / UINT
 // and pushes the result through the C ABI (upload()).  Same results as raytracer3_amd/assets.py; tests/test_host_assets.py
-// compares the two loaders array by array.  Progressive JPEG and EXR PXR24/B44/DWA are not decoded (reported as errors).
+// compares the two loaders array by array.  Arithmetic-coded / 12-bit / CMYK JPEG and EXR PXR24/B44/DWA are not decoded (reported as errors).
 #pragma once
 #include <zlib.h>
 
@@ -224,36 +224,26 @@ inline Image decode_png(const uint8_t* d, size_t n) {
         p += 12 + (size_t)len;
     }
     if (!w || !h) throw std::runtime_error("PNG: no IHDR");
-    if (interlace) throw std::runtime_error("PNG: Adam7 interlacing is not supported");
+    if (interlace > 1) throw std::runtime_error("PNG: unknown interlace method");
     const int chans = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!chans || !(depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) throw std::runtime_error("PNG: bad colour type / depth");
-    const size_t bpp_bits = (size_t)chans * depth, row = (w * bpp_bits + 7) / 8, bpp = bpp_bits >= 8 ? bpp_bits / 8 : 1;
-    std::vector<uint8_t> raw = inflate_all(idat.data(), idat.size(), (row + 1) * h);
-    if (raw.size() != (row + 1) * h) throw std::runtime_error("PNG: wrong amount of image data");
-    std::vector<uint8_t> img(row * h);
-    for (uint32_t y = 0; y < h; y++) {  // undo the per-row filters (PNG spec 9.2)
-        const uint8_t* in = raw.data() + (row + 1) * y;
-        uint8_t* cur = img.data() + row * y;
-        const uint8_t* up = y ? cur - row : nullptr;
-        const int ft = in[0];
-        for (size_t x = 0; x < row; x++) {
-            const int a = x >= bpp ? cur[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0;
-            int pred = 0;
-            switch (ft) {
-                case 0: pred = 0; break;
-                case 1: pred = a; break;
-                case 2: pred = b; break;
-                case 3: pred = (a + b) >> 1; break;
-                case 4: {
-                    const int pp = a + b - c, pa = std::abs(pp - a), pb = std::abs(pp - b), pc = std::abs(pp - c);
-                    pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-                    break;
-                }
-                default: throw std::runtime_error("PNG: bad filter type");
-            }
-            cur[x] = (uint8_t)(in[1 + x] + pred);
+    const size_t bpp_bits = (size_t)chans * depth, bpp = bpp_bits >= 8 ? bpp_bits / 8 : 1;
+    auto row_bytes = [&](uint32_t pw) { return ((size_t)pw * bpp_bits + 7) / 8; };
+    // the image is one pass, or the seven Adam7 passes (PNG spec 8.2): pass pixel (px, py) is image pixel (x0 + px * dx, y0 + py * dy)
+    struct Pass { uint32_t x0, y0, dx, dy, pw, ph; };
+    std::vector<Pass> passes;
+    if (!interlace) passes.push_back({0, 0, 1, 1, w, h});
+    else {
+        static const uint32_t a7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+        for (auto& a : a7) {
+            const uint32_t pw = w > a[0] ? (w - a[0] + a[2] - 1) / a[2] : 0, ph = h > a[1] ? (h - a[1] + a[3] - 1) / a[3] : 0;
+            if (pw && ph) passes.push_back({a[0], a[1], a[2], a[3], pw, ph});
         }
     }
+    size_t want = 0;
+    for (auto& ps : passes) want += (row_bytes(ps.pw) + 1) * ps.ph;
+    std::vector<uint8_t> raw = inflate_all(idat.data(), idat.size(), want);
+    if (raw.size() != want) throw std::runtime_error("PNG: wrong amount of image data");
     Image out;
     out.w = w;
     out.h = h;
@@ -265,37 +255,68 @@ inline Image decode_png(const uint8_t* d, size_t n) {
         return (r[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1u);
     };
     auto to8 = [&](uint32_t v) -> uint8_t { return depth == 16 ? (uint8_t)(v >> 8) : depth == 8 ? (uint8_t)v : (uint8_t)(v * 255u / ((1u << depth) - 1u)); };
-    for (uint32_t y = 0; y < h; y++) {
-        const uint8_t* r = img.data() + row * y;
-        for (uint32_t x = 0; x < w; x++) {
-            uint8_t* o = out.rgba.data() + 4 * ((size_t)y * w + x);
-            if (ctype == 3) {
-                const uint32_t i = sample(r, x);
-                if (3 * (size_t)i + 2 >= plte.size()) throw std::runtime_error("PNG: palette index out of range");
-                o[0] = plte[3 * i]; o[1] = plte[3 * i + 1]; o[2] = plte[3 * i + 2];
-                o[3] = i < trns.size() ? trns[i] : 255;
-            } else if (ctype == 0 || ctype == 4) {
-                const uint32_t g = sample(r, (size_t)x * chans);
-                o[0] = o[1] = o[2] = to8(g);
-                o[3] = ctype == 4 ? to8(sample(r, (size_t)x * chans + 1)) : 255;
-                if (ctype == 0 && trns.size() >= 2 && g == (((uint32_t)trns[0] << 8) | trns[1])) o[3] = 0;
-            } else {
-                const uint32_t R = sample(r, (size_t)x * chans), G = sample(r, (size_t)x * chans + 1), B = sample(r, (size_t)x * chans + 2);
-                o[0] = to8(R); o[1] = to8(G); o[2] = to8(B);
-                o[3] = ctype == 6 ? to8(sample(r, (size_t)x * chans + 3)) : 255;
-                if (ctype == 2 && trns.size() >= 6 && R == (((uint32_t)trns[0] << 8) | trns[1]) && G == (((uint32_t)trns[2] << 8) | trns[3]) &&
-                    B == (((uint32_t)trns[4] << 8) | trns[5]))
-                    o[3] = 0;
+    size_t off = 0;
+    for (auto& ps : passes) {
+        const size_t row = row_bytes(ps.pw);
+        std::vector<uint8_t> img(row * ps.ph);
+        for (uint32_t y = 0; y < ps.ph; y++) {  // undo the per-row filters (PNG spec 9.2)
+            const uint8_t* in = raw.data() + off + (row + 1) * y;
+            uint8_t* cur = img.data() + row * y;
+            const uint8_t* up = y ? cur - row : nullptr;
+            const int ft = in[0];
+            for (size_t x = 0; x < row; x++) {
+                const int a = x >= bpp ? cur[x - bpp] : 0, b = up ? up[x] : 0, c = (up && x >= bpp) ? up[x - bpp] : 0;
+                int pred = 0;
+                switch (ft) {
+                    case 0: pred = 0; break;
+                    case 1: pred = a; break;
+                    case 2: pred = b; break;
+                    case 3: pred = (a + b) >> 1; break;
+                    case 4: {
+                        const int pp = a + b - c, pa = std::abs(pp - a), pb = std::abs(pp - b), pc = std::abs(pp - c);
+                        pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                        break;
+                    }
+                    default: throw std::runtime_error("PNG: bad filter type");
+                }
+                cur[x] = (uint8_t)(in[1 + x] + pred);
+            }
+        }
+        off += (row + 1) * ps.ph;
+        for (uint32_t py = 0; py < ps.ph; py++) {
+            const uint8_t* r = img.data() + row * py;
+            for (uint32_t x = 0; x < ps.pw; x++) {
+                uint8_t* o = out.rgba.data() + 4 * ((size_t)(ps.y0 + py * ps.dy) * w + ps.x0 + x * ps.dx);
+                if (ctype == 3) {
+                    const uint32_t i = sample(r, x);
+                    if (3 * (size_t)i + 2 >= plte.size()) throw std::runtime_error("PNG: palette index out of range");
+                    o[0] = plte[3 * i]; o[1] = plte[3 * i + 1]; o[2] = plte[3 * i + 2];
+                    o[3] = i < trns.size() ? trns[i] : 255;
+                } else if (ctype == 0 || ctype == 4) {
+                    const uint32_t g = sample(r, (size_t)x * chans);
+                    o[0] = o[1] = o[2] = to8(g);
+                    o[3] = ctype == 4 ? to8(sample(r, (size_t)x * chans + 1)) : 255;
+                    if (ctype == 0 && trns.size() >= 2 && g == (((uint32_t)trns[0] << 8) | trns[1])) o[3] = 0;
+                } else {
+                    const uint32_t R = sample(r, (size_t)x * chans), G = sample(r, (size_t)x * chans + 1), B = sample(r, (size_t)x * chans + 2);
+                    o[0] = to8(R); o[1] = to8(G); o[2] = to8(B);
+                    o[3] = ctype == 6 ? to8(sample(r, (size_t)x * chans + 3)) : 255;
+                    if (ctype == 2 && trns.size() >= 6 && R == (((uint32_t)trns[0] << 8) | trns[1]) && G == (((uint32_t)trns[2] << 8) | trns[3]) &&
+                        B == (((uint32_t)trns[4] << 8) | trns[5]))
+                        o[3] = 0;
+                }
             }
         }
     }
     return out;
 }
 
-// ------------------------------------------------------------------------------------------------ baseline JPEG -> RGBA8
-// ITU T.81 baseline sequential DCT, Huffman coded, 8-bit, 1 or 3 components (JFIF YCbCr), sampling factors 1 or 2, restart
-// intervals.  Progressive / arithmetic / 12-bit / CMYK files are reported as unsupported.  Chroma is upsampled by replication
-// (libjpeg's default "fancy" triangle filter differs from this by a few levels along sharp chroma edges).
+// ------------------------------------------------------------------------------------------------ JPEG -> RGBA8
+// ITU T.81 Huffman-coded DCT JPEG, 8-bit, 1 or 3 components (JFIF YCbCr), sampling factors 1 or 2, restart intervals:
+// baseline / extended sequential (SOF0 / SOF1, interleaved or one scan per component) and progressive (SOF2: spectral selection and
+// successive approximation, T.81 annex G).  Coefficients are collected over all scans, then dequantised and inverse-transformed once.
+// Arithmetic-coded / lossless / 12-bit / CMYK files are reported as unsupported.  Chroma is upsampled by replication (libjpeg's
+// default "fancy" triangle filter differs from this by a few levels along sharp chroma edges).
 class JpegDecoder {
   public:
     static Image decode(const uint8_t* d, size_t n) {
@@ -311,17 +332,34 @@ class JpegDecoder {
         int mincode[17], maxcode[18], valptr[17];
         bool present = false;
     } dc_[4], ac_[4];
-    uint16_t qt_[4][64] = {{0}};
-    struct Comp { int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0; std::vector<uint8_t> plane; int pw = 0, ph = 0; } comp_[3];
-    int ncomp_ = 0, width_ = 0, height_ = 0, restart_ = 0;
+    uint16_t qt_[4][64] = {{0}};  // zig-zag order, as stored in the file
+    bool qt_present_[4] = {false, false, false, false};
+    struct Comp {
+        int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0, pred = 0;
+        int bw = 0, bh = 0;      // blocks per row / column of the MCU-padded plane
+        int cw = 0, ch = 0;      // blocks that cover the component itself (geometry of a single-component scan)
+        std::vector<int16_t> coef;  // bw * bh * 64, natural (row-major) order within a block
+        uint16_t q[64] = {0};    // natural order; captured at the component's first scan
+        bool q_set = false;
+        std::vector<uint8_t> plane;
+        int pw = 0, ph = 0;
+    } comp_[3];
+    int ncomp_ = 0, width_ = 0, height_ = 0, restart_ = 0, hmax_ = 1, vmax_ = 1, mcux_ = 0, mcuy_ = 0;
+    bool progressive_ = false;
     uint32_t bitbuf_ = 0;
     int bitcnt_ = 0;
     bool hit_marker_ = false;
+    int eobrun_ = 0;
 
     JpegDecoder(const uint8_t* d, size_t n) : d_(d), n_(n) {}
     [[noreturn]] static void fail(const char* w) { throw std::runtime_error(std::string("JPEG: ") + w); }
     int u8() { if (p_ >= n_) fail("truncated"); return d_[p_++]; }
     int u16() { int a = u8(); return (a << 8) | u8(); }
+    static const uint8_t* zigzag() {
+        static const uint8_t zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
+                                       35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+        return zz;
+    }
 
     static void build(Huff& h) {
         int code = 0, k = 0;
@@ -390,14 +428,13 @@ class JpegDecoder {
                 out[y * stride + x] = (uint8_t)(q < 0 ? 0 : (q > 255 ? 255 : q));
             }
     }
-    void block(Comp& c, int bx, int by) {
-        static const uint8_t zz[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28,
-                                       35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
-        float coef[64] = {0};
-        const uint16_t* q = qt_[c.tq];
-        int t = decode_sym(dc_[c.td]);
+
+    // ---- one block of one scan.  ss..se = spectral band, ah / al = successive-approximation bit positions (0,63,0,0 when sequential)
+    void block_sequential(Comp& c, int16_t* coef) {
+        const uint8_t* zz = zigzag();
+        const int t = decode_sym(dc_[c.td]);
         c.pred += extend(receive(t), t);
-        coef[0] = (float)(c.pred * (int)q[0]);
+        coef[0] = (int16_t)c.pred;
         for (int k = 1; k < 64;) {
             const int rs = decode_sym(ac_[c.ta]), r = rs >> 4, s = rs & 15;
             if (s == 0) {
@@ -406,29 +443,177 @@ class JpegDecoder {
             }
             k += r;
             if (k > 63) fail("bad AC run");
-            coef[zz[k]] = (float)(extend(receive(s), s) * (int)q[k]);
+            coef[zz[k]] = (int16_t)extend(receive(s), s);
             k++;
         }
-        idct8x8(coef, c.plane.data() + (size_t)(8 * by) * c.pw + 8 * bx, c.pw);
+    }
+    void block_dc_first(Comp& c, int16_t* coef, int al) {  // G.1.2.1
+        const int t = decode_sym(dc_[c.td]);
+        c.pred += extend(receive(t), t);
+        coef[0] = (int16_t)(c.pred * (1 << al));
+    }
+    void block_dc_refine(int16_t* coef, int al) {
+        if (getbit()) coef[0] = (int16_t)(coef[0] | (1 << al));
+    }
+    void block_ac_first(Comp& c, int16_t* coef, int ss, int se, int al) {  // G.1.2.2
+        const uint8_t* zz = zigzag();
+        if (eobrun_ > 0) {
+            eobrun_--;
+            return;
+        }
+        for (int k = ss; k <= se;) {
+            const int rs = decode_sym(ac_[c.ta]), r = rs >> 4, s = rs & 15;
+            if (s == 0) {
+                if (r < 15) {  // EOBn: this band ends here for 2^r (+ extra bits) blocks, this one included
+                    eobrun_ = (1 << r) - 1;
+                    if (r) eobrun_ += receive(r);
+                    break;
+                }
+                k += 16;
+            } else {
+                k += r;
+                if (k > se) fail("bad AC run");
+                coef[zz[k]] = (int16_t)(extend(receive(s), s) * (1 << al));
+                k++;
+            }
+        }
+    }
+    void block_ac_refine(Comp& c, int16_t* coef, int ss, int se, int al) {  // G.1.2.3
+        const uint8_t* zz = zigzag();
+        const int p1 = 1 << al, m1 = -(1 << al);
+        auto correct = [&](int16_t& v) {
+            if (getbit() && (v & p1) == 0) v = (int16_t)(v + (v >= 0 ? p1 : m1));
+        };
+        int k = ss;
+        if (eobrun_ == 0) {
+            for (; k <= se; k++) {
+                const int rs = decode_sym(ac_[c.ta]);
+                int r = rs >> 4, s = rs & 15;
+                if (s) {
+                    if (s != 1) fail("bad refinement code");
+                    s = getbit() ? p1 : m1;
+                } else if (r != 15) {
+                    eobrun_ = 1 << r;
+                    if (r) eobrun_ += receive(r);
+                    break;
+                }
+                // skip r zero-history coefficients; every nonzero-history one on the way takes a correction bit
+                for (; k <= se; k++) {
+                    int16_t& v = coef[zz[k]];
+                    if (v != 0) correct(v);
+                    else if (--r < 0) break;
+                }
+                if (s) {
+                    if (k > se) fail("bad refinement run");
+                    coef[zz[k]] = (int16_t)s;
+                }
+            }
+        }
+        if (eobrun_ > 0) {
+            for (; k <= se; k++) {
+                int16_t& v = coef[zz[k]];
+                if (v != 0) correct(v);
+            }
+            eobrun_--;
+        }
+    }
+
+    void setup_frame() {
+        hmax_ = vmax_ = 1;
+        for (int i = 0; i < ncomp_; i++) { hmax_ = std::max(hmax_, comp_[i].h); vmax_ = std::max(vmax_, comp_[i].v); }
+        if (ncomp_ == 1) { comp_[0].h = comp_[0].v = 1; hmax_ = vmax_ = 1; }
+        mcux_ = (width_ + 8 * hmax_ - 1) / (8 * hmax_);
+        mcuy_ = (height_ + 8 * vmax_ - 1) / (8 * vmax_);
+        for (int i = 0; i < ncomp_; i++) {
+            Comp& c = comp_[i];
+            c.bw = mcux_ * c.h;
+            c.bh = mcuy_ * c.v;
+            const int cwid = (width_ * c.h + hmax_ - 1) / hmax_, chei = (height_ * c.v + vmax_ - 1) / vmax_;
+            c.cw = (cwid + 7) / 8;
+            c.ch = (chei + 7) / 8;
+            c.coef.assign((size_t)c.bw * c.bh * 64, 0);
+        }
+    }
+    void restart_marker(const std::vector<int>& sc) {  // RSTn: byte-align, skip the marker, reset predictors and the EOB run
+        bitcnt_ = 0;
+        hit_marker_ = false;
+        while (p_ + 1 < n_ && !(d_[p_] == 0xFF && d_[p_ + 1] >= 0xD0 && d_[p_ + 1] <= 0xD7)) p_++;
+        p_ += 2;
+        for (int ci : sc) comp_[ci].pred = 0;
+        eobrun_ = 0;
+    }
+    void scan(const std::vector<int>& sc, int ss, int se, int ah, int al) {
+        for (int ci : sc) {
+            Comp& c = comp_[ci];
+            c.pred = 0;
+            if (!c.q_set) {
+                if (!qt_present_[c.tq]) fail("missing quantisation table");
+                for (int k = 0; k < 64; k++) c.q[zigzag()[k]] = qt_[c.tq][k];
+                c.q_set = true;
+            }
+            const bool need_dc = ss == 0 && (!progressive_ || ah == 0), need_ac = se > 0;
+            if ((need_dc && !dc_[c.td].present) || (need_ac && !ac_[c.ta].present)) fail("missing Huffman table");
+        }
+        bitcnt_ = 0;
+        hit_marker_ = false;
+        eobrun_ = 0;
+        auto one = [&](Comp& c, int bx, int by) {
+            int16_t* coef = c.coef.data() + ((size_t)by * c.bw + bx) * 64;
+            if (!progressive_) block_sequential(c, coef);
+            else if (ss == 0) ah == 0 ? block_dc_first(c, coef, al) : block_dc_refine(coef, al);
+            else ah == 0 ? block_ac_first(c, coef, ss, se, al) : block_ac_refine(c, coef, ss, se, al);
+        };
+        int left = restart_;
+        if (sc.size() == 1) {  // single-component scan: the component's own blocks in raster order, one block per "MCU"
+            Comp& c = comp_[sc[0]];
+            for (int by = 0; by < c.ch; by++)
+                for (int bx = 0; bx < c.cw; bx++) {
+                    if (restart_ && left == 0) { restart_marker(sc); left = restart_; }
+                    one(c, bx, by);
+                    if (restart_) left--;
+                }
+        } else {
+            for (int my = 0; my < mcuy_; my++)
+                for (int mx = 0; mx < mcux_; mx++) {
+                    if (restart_ && left == 0) { restart_marker(sc); left = restart_; }
+                    for (int ci : sc) {
+                        Comp& c = comp_[ci];
+                        for (int by = 0; by < c.v; by++)
+                            for (int bx = 0; bx < c.h; bx++) one(c, mx * c.h + bx, my * c.v + by);
+                    }
+                    if (restart_) left--;
+                }
+        }
+        // leave p_ on the next marker
+        if (!hit_marker_)
+            while (p_ + 1 < n_ && !(d_[p_] == 0xFF && d_[p_ + 1] != 0 && !(d_[p_ + 1] >= 0xD0 && d_[p_ + 1] <= 0xD7))) p_++;
     }
     Image run() {
         if (n_ < 4 || d_[0] != 0xFF || d_[1] != 0xD8) fail("no SOI marker");
         p_ = 2;
-        bool have_frame = false;
+        bool have_frame = false, have_scan = false;
         for (;;) {
+            if (p_ >= n_) {
+                if (have_scan) break;  // tolerate a missing EOI
+                fail("truncated");
+            }
             int m = u8();
             if (m != 0xFF) continue;
-            while ((m = u8()) == 0xFF) {}
-            if (m == 0xD9) fail("no scan before EOI");
-            if (m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+            while (p_ < n_ && (m = u8()) == 0xFF) {}
+            if (m == 0xD9) {
+                if (!have_scan) fail("no scan before EOI");
+                break;
+            }
+            if (m == 0 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
             const int len = u16();
             const size_t end = p_ + (size_t)len - 2;
-            if (end > n_) fail("truncated segment");
+            if (len < 2 || end > n_) fail("truncated segment");
             if (m == 0xDB) {
                 while (p_ < end) {
                     const int pq = u8(), t = pq & 15;
                     if (t > 3) fail("bad quantisation table id");
-                    for (int k = 0; k < 64; k++) qt_[t][k] = (uint16_t)((pq >> 4) ? u16() : u8());  // stored in zig-zag order
+                    for (int k = 0; k < 64; k++) qt_[t][k] = (uint16_t)((pq >> 4) ? u16() : u8());
+                    qt_present_[t] = true;
                 }
             } else if (m == 0xC4) {
                 while (p_ < end) {
@@ -441,7 +626,9 @@ class JpegDecoder {
                     for (int k = 0; k < total; k++) h.vals[k] = (uint8_t)u8();
                     build(h);
                 }
-            } else if (m == 0xC0 || m == 0xC1) {
+            } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+                if (have_frame) fail("more than one frame header");
+                progressive_ = m == 0xC2;
                 if (u8() != 8) fail("only 8-bit samples are supported");
                 height_ = u16();
                 width_ = u16();
@@ -455,15 +642,17 @@ class JpegDecoder {
                     comp_[i].tq = u8();
                     if (comp_[i].h < 1 || comp_[i].h > 2 || comp_[i].v < 1 || comp_[i].v > 2 || comp_[i].tq > 3) fail("unsupported sampling factors");
                 }
+                setup_frame();
                 have_frame = true;
-            } else if (m == 0xC2 || (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC)) {
-                fail("progressive / lossless / arithmetic-coded JPEG is not supported (baseline only)");
+            } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+                fail("lossless / hierarchical / arithmetic-coded JPEG is not supported");
             } else if (m == 0xDD) {
                 restart_ = u16();
             } else if (m == 0xDA) {
                 if (!have_frame) fail("scan before frame header");
                 const int ns = u8();
-                if (ns != ncomp_) fail("non-interleaved scans are not supported");
+                if (ns < 1 || ns > ncomp_) fail("bad component count in scan header");
+                std::vector<int> sc;
                 for (int i = 0; i < ns; i++) {
                     const int id = u8(), tt = u8();
                     int ci = -1;
@@ -472,41 +661,38 @@ class JpegDecoder {
                     if (ci < 0) fail("scan references an unknown component");
                     comp_[ci].td = tt >> 4;
                     comp_[ci].ta = tt & 15;
-                    if (comp_[ci].td > 3 || comp_[ci].ta > 3 || !dc_[comp_[ci].td].present || !ac_[comp_[ci].ta].present) fail("missing Huffman table");
+                    if (comp_[ci].td > 3 || comp_[ci].ta > 3) fail("bad Huffman table id");
+                    sc.push_back(ci);
                 }
+                int ss = u8(), se = u8();
+                const int a = u8(), ah = a >> 4, al = a & 15;
+                if (!progressive_) { ss = 0; se = 63; }
+                else if (ss > se || se > 63 || (ss == 0 && se != 0) || (ss > 0 && ns != 1) || al > 13) fail("bad progressive scan parameters");
                 p_ = end;
-                return scan();
+                scan(sc, ss, se, progressive_ ? ah : 0, progressive_ ? al : 0);
+                have_scan = true;
+                continue;
             }
             p_ = end;
         }
+        return finish();
     }
-    Image scan() {
-        int hmax = 1, vmax = 1;
-        for (int i = 0; i < ncomp_; i++) { hmax = std::max(hmax, comp_[i].h); vmax = std::max(vmax, comp_[i].v); }
-        if (ncomp_ == 1) { comp_[0].h = comp_[0].v = 1; hmax = vmax = 1; }
-        const int mcux = (width_ + 8 * hmax - 1) / (8 * hmax), mcuy = (height_ + 8 * vmax - 1) / (8 * vmax);
+    Image finish() {
         for (int i = 0; i < ncomp_; i++) {
-            comp_[i].pw = mcux * comp_[i].h * 8;
-            comp_[i].ph = mcuy * comp_[i].v * 8;
-            comp_[i].plane.assign((size_t)comp_[i].pw * comp_[i].ph, 0);
-            comp_[i].pred = 0;
-        }
-        int left = restart_;
-        for (int my = 0; my < mcuy; my++)
-            for (int mx = 0; mx < mcux; mx++) {
-                if (restart_ && left == 0) {  // RSTn: byte-align, skip the marker, reset the predictors
-                    bitcnt_ = 0;
-                    hit_marker_ = false;
-                    while (p_ + 1 < n_ && !(d_[p_] == 0xFF && d_[p_ + 1] >= 0xD0 && d_[p_ + 1] <= 0xD7)) p_++;
-                    p_ += 2;
-                    for (int i = 0; i < ncomp_; i++) comp_[i].pred = 0;
-                    left = restart_;
+            Comp& c = comp_[i];
+            if (!c.q_set) fail("a component has no scan");
+            c.pw = c.bw * 8;
+            c.ph = c.bh * 8;
+            c.plane.assign((size_t)c.pw * c.ph, 0);
+            float f[64];
+            for (int by = 0; by < c.bh; by++)
+                for (int bx = 0; bx < c.bw; bx++) {
+                    const int16_t* coef = c.coef.data() + ((size_t)by * c.bw + bx) * 64;
+                    for (int k = 0; k < 64; k++) f[k] = (float)((int)coef[k] * (int)c.q[k]);
+                    idct8x8(f, c.plane.data() + (size_t)(8 * by) * c.pw + 8 * bx, c.pw);
                 }
-                for (int i = 0; i < ncomp_; i++)
-                    for (int by = 0; by < comp_[i].v; by++)
-                        for (int bx = 0; bx < comp_[i].h; bx++) block(comp_[i], mx * comp_[i].h + bx, my * comp_[i].v + by);
-                if (restart_) left--;
-            }
+        }
+        const int hmax = hmax_, vmax = vmax_;
         Image out;
         out.w = (uint32_t)width_;
         out.h = (uint32_t)height_;
@@ -529,7 +715,7 @@ class JpegDecoder {
         return out;
     }
 };
-// PNG or baseline JPEG, by signature
+// PNG or JPEG, by signature
 inline Image decode_image(const uint8_t* d, size_t n) {
     if (n >= 2 && d[0] == 0xFF && d[1] == 0xD8) return JpegDecoder::decode(d, n);
     return decode_png(d, n);

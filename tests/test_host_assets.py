@@ -157,11 +157,13 @@ def test_png_decoder_matches_pillow(tool, tmp_path, mode):
     assert np.array_equal(got, np.array(Image.open(p).convert("RGBA"), np.uint8))
 
 
+@pytest.mark.parametrize("progressive", [False, True])
 @pytest.mark.parametrize("mode,subsampling,restart", [("RGB", 0, 0), ("RGB", 2, 0), ("RGB", 1, 0), ("L", 0, 0), ("RGB", 2, 3)])
-def test_jpeg_decoder_tracks_pillow(tool, tmp_path, mode, subsampling, restart):
-    """Baseline JPEG (what glTF scenes ship next to PNG).  Decoders differ legitimately in the IDCT and in chroma upsampling
-    (libjpeg-turbo interpolates, this one replicates), so the comparison has a tolerance: tight for 4:4:4 / grey, loose
-    along chroma edges for 4:2:2 / 4:2:0."""
+def test_jpeg_decoder_tracks_pillow(tool, tmp_path, mode, subsampling, restart, progressive):
+    """Baseline and progressive JPEG (what glTF scenes ship next to PNG; libjpeg's progressive script has DC and AC scans with
+    successive-approximation refinement).  Decoders differ legitimately in the IDCT and in chroma upsampling (libjpeg-turbo
+    interpolates, this one replicates), so the comparison has a tolerance: tight for 4:4:4 / grey, loose along chroma edges
+    for 4:2:2 / 4:2:0."""
     from PIL import Image
 
     yy, xx = np.mgrid[0:75, 0:101]
@@ -169,7 +171,7 @@ def test_jpeg_decoder_tracks_pillow(tool, tmp_path, mode, subsampling, restart):
     img[20:40, 30:60] = [250, 20, 30]  # a sharp coloured block
     im = Image.fromarray(img, "RGB").convert(mode)
     p = tmp_path / "t.jpg"
-    kw = dict(quality=92, subsampling=subsampling)
+    kw = dict(quality=92, subsampling=subsampling, progressive=progressive)
     if restart:
         kw["restart_marker_rows"] = restart
     try:
@@ -313,7 +315,92 @@ def test_loader_errors_are_reported(tool, tmp_path):
     assert r.returncode == 1 and "not a PNG" in r.stderr
     from PIL import Image
 
-    prog = tmp_path / "prog.jpg"
-    Image.fromarray(np.zeros((16, 16, 3), np.uint8), "RGB").save(prog, format="JPEG", progressive=True)
-    r = subprocess.run([tool, "png", str(prog), str(tmp_path)], capture_output=True, text=True)
-    assert r.returncode == 1 and "progressive" in r.stderr
+    cmyk = tmp_path / "cmyk.jpg"
+    Image.fromarray(np.zeros((16, 16, 4), np.uint8), "CMYK").save(cmyk, format="JPEG")
+    r = subprocess.run([tool, "png", str(cmyk), str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 1 and "1- and 3-component" in r.stderr
+    cut = tmp_path / "cut.jpg"
+    Image.fromarray(np.full((40, 40, 3), 90, np.uint8), "RGB").save(cut, format="JPEG", progressive=True)
+    cut.write_bytes(cut.read_bytes()[:120])
+    r = subprocess.run([tool, "png", str(cut), str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 1 and "JPEG" in r.stderr
+
+
+@pytest.mark.parametrize("quality", [35, 75, 98])
+def test_jpeg_progressive_on_noise(tool, tmp_path, quality):
+    """Noise at several qualities: long zero runs and EOB runs at low quality, dense refinement scans at high quality; 4:4:4 so
+    that only the IDCT separates the two decoders.  The same pixels saved baseline must decode to the same result here."""
+    from PIL import Image
+
+    rng = np.random.default_rng(quality)
+    img = (rng.normal(128, 50, (43, 67, 3)) + 60 * np.sin(np.arange(67) / 5.0)[None, :, None]).clip(0, 255).astype(np.uint8)
+    outs = []
+    for progressive in (True, False):
+        p = tmp_path / f"n{int(progressive)}.jpg"
+        Image.fromarray(img, "RGB").save(p, format="JPEG", quality=quality, subsampling=0, progressive=progressive)
+        run(tool, "png", p, tmp_path)
+        got = np.fromfile(tmp_path / "image.bin", np.uint8).reshape(43, 67, 4).astype(np.int32)
+        want = np.array(Image.open(p).convert("RGBA"), np.uint8).astype(np.int32)
+        diff = np.abs(got[..., :3] - want[..., :3])
+        assert diff.max() <= 3 and diff.mean() < 0.6, (progressive, diff.max(), diff.mean())
+        outs.append(got)
+    assert np.array_equal(outs[0], outs[1])  # same quantised coefficients, whichever way they were transmitted
+
+
+def _write_adam7_png(path, arr, ctype, depth):
+    """Minimal Adam7 PNG writer (Pillow cannot write interlaced files): arr = (h, w, channels) samples of `depth` bits;
+    rows alternate the None and Sub filters so that un-filtering is exercised inside the passes."""
+    import zlib
+
+    h, w, ch = arr.shape
+
+    def chunk(typ, body):
+        return struct.pack(">I", len(body)) + typ + body + struct.pack(">I", zlib.crc32(typ + body) & 0xFFFFFFFF)
+
+    def pack_row(samples):  # (pw, ch) -> bytes
+        flat = samples.reshape(-1).astype(np.uint32)
+        if depth == 16:
+            return flat.astype(">u2").tobytes()
+        if depth == 8:
+            return flat.astype(np.uint8).tobytes()
+        bits = np.zeros(((len(flat) * depth + 7) // 8) * 8, np.uint8)
+        for b in range(depth):
+            bits[b : len(flat) * depth : depth] = (flat >> (depth - 1 - b)) & 1
+        return np.packbits(bits).tobytes()
+
+    bpp = max(1, ch * depth // 8)
+    raw = bytearray()
+    for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+        sub = arr[y0::dy, x0::dx]
+        if sub.shape[0] == 0 or sub.shape[1] == 0:
+            continue
+        for k, r in enumerate(sub):
+            line = np.frombuffer(pack_row(r), np.uint8)
+            if k % 2:  # Sub filter
+                prev = np.concatenate([np.zeros(bpp, np.uint8), line[:-bpp]]) if len(line) > bpp else np.zeros(len(line), np.uint8)
+                raw += b"\x01" + ((line.astype(np.int32) - prev) % 256).astype(np.uint8).tobytes()
+            else:
+                raw += b"\x00" + line.tobytes()
+    ihdr = struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1)
+    Path(path).write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", zlib.compress(bytes(raw))) + chunk(b"IEND", b""))
+
+
+@pytest.mark.parametrize("ctype,depth,shape", [(6, 8, (37, 53)), (2, 8, (9, 5)), (0, 16, (20, 33)), (0, 1, (13, 29)), (4, 8, (8, 8)), (2, 16, (3, 2)), (0, 4, (1, 1))])
+def test_png_adam7_matches_pillow(tool, tmp_path, ctype, depth, shape):
+    """Interlaced PNG (the `image` crate reads them): all seven passes incl. the ones that vanish for tiny images."""
+    from PIL import Image
+
+    h, w = shape
+    ch = {0: 1, 2: 3, 4: 2, 6: 4}[ctype]
+    arr = np.random.default_rng(ctype * 100 + depth).integers(0, 1 << depth, (h, w, ch))
+    p = tmp_path / "i.png"
+    _write_adam7_png(p, arr, ctype, depth)
+    im = Image.open(p)
+    assert im.info.get("interlace") == 1
+    want = np.array(im.convert("RGBA"), np.uint8)
+    run(tool, "png", p, tmp_path)
+    got = np.fromfile(tmp_path / "image.bin", np.uint8).reshape(h, w, 4)
+    if depth == 16:  # Pillow converts 16-bit grey through its own scaling; compare with the spec's >> 8 directly
+        ref = (arr >> 8).astype(np.uint8)
+        want = np.concatenate([np.repeat(ref[..., :1], 3, -1) if ch < 3 else ref[..., :3], np.full((h, w, 1), 255, np.uint8)], -1)
+    assert np.array_equal(got, want)
