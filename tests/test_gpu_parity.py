@@ -607,3 +607,95 @@ def test_lbvh_large_scene_bit_identical():
     ot, ou, ov, op, ocn, oct = osc.trace_closest(rays, counts=True, threads=16)
     assert np.array_equal(p, op) and np.array_equal(t[p != L.MISS], ot[p != L.MISS]) and np.array_equal(cn, ocn) and np.array_equal(ct, oct)
     ctx.close()
+
+
+# ---- BASELINE.json configs, by name (C3 = test_full_size_frame_properties + the bit-exact crop of bench.py)
+def test_config_c1_primary_visibility_256():
+    """configs[0]: primary visibility only, 256 x 256 @ 1 spp -- the gbuffer pass against the oracle, every texel."""
+    mesh = scenes.atrium(1.0)
+    osc = orc.Scene(mesh)
+    pt = PathTracer((256, 256))
+    pt.set_scene(mesh)
+    cam = Camera(scenes.ATRIUM_CAMERA["position"], scenes.ATRIUM_CAMERA["direction"], math.radians(scenes.ATRIUM_CAMERA["fov_deg"]), 1.0)
+    g = pt.make_gconst(cam, 1, 1, flags=0)
+    h = pt.commands(g, postprocess=False)
+    b = (C.c_uint32 * 2)(h["gbuffer"], h["depth"])  # the gbuffer node alone
+    pt.ctx.check(pt.ctx.lib.rt3_pass_launch(pt.ctx.h, b"gbuffer", b"main", 256, 256, 1, C.byref(g), C.sizeof(g), b, 2))
+    pt.ctx.wait()
+    gb, depth = pt.gbuffer()
+    st = pt.ctx.stats()
+    pt.close()
+    ogb, odepth = osc.gbuffer(as_orc(g), threads=16)
+    hit = odepth != orc.BACKGROUND_DEPTH
+    assert np.array_equal(depth.view(np.uint32), odepth.view(np.uint32)) and np.array_equal(gb[hit], ogb[hit])
+    assert st.extension_rays == 256 * 256 and st.shadow_rays == 0 and 0.5 < hit.mean() < 1.0
+
+
+def test_config_c2_1080p_direct_light_whole_frame():
+    """configs[1]: 1920 x 1080 @ 1 spp, BVH traversal + direct light only (one bounce: emission + sky NEE with its shadow ray),
+    the WHOLE frame bit for bit against the oracle (2.07 M primary + ~1 M shadow rays: about a second on the host cores)."""
+    W, H = 1920, 1080
+    mesh, sky, bn = scenes.atrium(1.0), scenes.sky(2048, 1024), assets.load_bluenoise()
+    g, light, gb, depth, _, st = render_both(mesh, sky, bn, None, W, H, scenes.ATRIUM_CAMERA, 1, 1, SPEC, frame=11)
+    osc = orc.Scene(mesh, sky, bn)
+    og = as_orc(g)
+    ogb, odepth = osc.gbuffer(og, threads=16)
+    assert np.array_equal(depth.view(np.uint32), odepth.view(np.uint32))
+    olight, counts = osc.reference_mode(og, ogb, odepth, threads=16)
+    assert np.array_equal(light.view(np.uint32), olight.view(np.uint32))
+    assert st.extension_rays == W * H + int(counts[0]) and st.shadow_rays == int(counts[1]) and st.shadow_rays > 500_000
+
+
+def test_config_c4_one_rank_of_eight_at_4k_256spp():
+    """configs[3]: 3840 x 2160 @ 256 spp tile-split over 8 GPUs -- the share of ONE rank at full size (1.04 M pixels, 265 M paths,
+    a single wavefront batch), two of its 64 x 64 tiles bit for bit against the oracle, and nothing written outside its tiles."""
+    W, H, spp, B, rank, n_ranks = 3840, 2160, 256, 4, 3, 8
+    mesh, sky, bn = scenes.atrium(1.0), scenes.sky(2048, 1024), assets.load_bluenoise()
+    pt = PathTracer((W, H), rank=rank, n_ranks=n_ranks)
+    pt.set_scene(mesh, sky, bn)
+    cam = Camera(scenes.ATRIUM_CAMERA["position"], scenes.ATRIUM_CAMERA["direction"], math.radians(scenes.ATRIUM_CAMERA["fov_deg"]), W / H)
+    g = pt.make_gconst(cam, spp, B, frame=2, flags=SPEC)
+    pt.render(g)
+    light = pt.light()
+    st = pt.ctx.stats()
+    pt.close()
+    xy = orc.tile_pixels(W, H, rank, n_ranks)
+    assert abs(len(xy) - W * H / n_ranks) < 0.02 * W * H / n_ranks
+    mine = np.zeros((H, W), bool)
+    mine[xy[:, 1], xy[:, 0]] = True
+    assert (light[~mine] == 0).all() and np.isfinite(light).all() and st.extension_rays > 5e8
+    osc = orc.Scene(mesh, sky, bn)
+    og = as_orc(g)
+    for k in (0, len(xy) // 2):  # the first pixel of a tile in render order is its top-left corner
+        x0, y0 = int(xy[k, 0]) // 64 * 64, int(xy[k, 1]) // 64 * 64
+        rect = (x0, y0, min(x0 + 64, W), min(y0 + 64, H))
+        ogb, odepth = osc.gbuffer(og, rect=rect, threads=16)
+        olight, _ = osc.reference_mode(og, ogb, odepth, rect=rect, threads=16)
+        assert mine[y0:rect[3], x0:rect[2]].all()
+        assert np.array_equal(olight[y0:rect[3], x0:rect[2]].view(np.uint32), light[y0:rect[3], x0:rect[2]].view(np.uint32))
+
+
+def test_config_c5_progressive_accumulation_is_a_running_mean():
+    """configs[4]: progressive accumulation (Light = lerp(PrevLight, pass, 1 / (p + 1))) at 4K.  Property at full size: after P passes
+    the image equals the sequentially blended per-pass images (each pass rendered on its own with blendfactor 1), in fp32 with the
+    shader's own lerp -- so the 4096-spp curve of tools/render.py is the running mean it claims to be."""
+    W, H, spp, P = 3840, 2160, 2, 3
+    mesh, sky, bn = scenes.atrium(1.0), scenes.sky(2048, 1024), assets.load_bluenoise()
+    cam = Camera(scenes.ATRIUM_CAMERA["position"], scenes.ATRIUM_CAMERA["direction"], math.radians(scenes.ATRIUM_CAMERA["fov_deg"]), W / H)
+    pt = PathTracer((W, H))
+    pt.set_scene(mesh, sky, bn)
+    singles = []
+    for p in range(P):
+        pt.render(pt.make_gconst(cam, spp, 3, frame=p, blendfactor=1.0, flags=SPEC))
+        singles.append(pt.light()[..., :3].copy())
+    pt.rg.upload(pt.handles["prev"], np.zeros((H, W, 4), np.float32))
+    for p in range(P):
+        pt.render(pt.make_gconst(cam, spp, 3, frame=p, blendfactor=1.0 / (p + 1), flags=SPEC))
+        pt.copy_light_to_prev()
+    acc = pt.light()[..., :3]
+    pt.close()
+    want = np.zeros_like(singles[0])
+    for p in range(P):
+        f = np.float32(1.0 / (p + 1))
+        want = want + (singles[p] - want) * f
+    assert np.allclose(acc, want, rtol=2e-6, atol=1e-7) and np.abs(acc - np.mean(singles, 0)).max() < 1e-3 * max(1.0, float(acc.max()))
