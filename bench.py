@@ -203,6 +203,7 @@ def main():
             traffic_src = f"profiles/{tfiles[-1].name}: {tj['correction']}"
     roofline = {
         "kernel": dom_name, "bound": "hbm", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s", "frac": round(achieved / peak, 4),
+        "frac_of_measured_copy_peak": round(achieved / 6290.0, 4),  # 6.29 TB/s float4 copy (MI355X_MICROARCH.md); SURVEY 8d asks for both
         "traffic": traffic, "traffic_source": traffic_src,
         "launches_per_frame": dom_launches, "avg_launch_ms": round(dom_ms / max(dom_launches, 1), 4),
         "algorithmic_bytes_per_launch": round(dom_bytes / max(dom_launches, 1)), "rays_per_launch": round(dom_rays / max(dom_launches, 1)),
