@@ -461,8 +461,8 @@ def test_cpp_host_renders_the_same_frame(small, tmp_path):
 
 def test_native_asset_pipeline_renders_the_oracle_frame(tmp_path):
     """Files in, pixels out, no Python in between: asset_tool (C++: glTF + PNG + EXR decoders -> C ABI -> pass graph) renders
-    a textured scene from a .glb, a ZIP-compressed .exr and the reference's bluenoise.png; the oracle, fed by the Python
-    loaders from the same files, must agree bit for bit."""
+    a textured scene from a .glb, a PIZ-compressed HALF .exr (what HDRI tools usually write) and the reference's bluenoise.png;
+    the oracle, fed by the Python loaders from the same files, must agree bit for bit."""
     import subprocess
     from pathlib import Path
 
@@ -471,7 +471,7 @@ def test_native_asset_pipeline_renders_the_oracle_frame(tmp_path):
     mesh = scenes.textured_cornell()
     glb, exr = tmp_path / "scene.glb", tmp_path / "sky.exr"
     assets.write_glb(glb, mesh)
-    assets.write_exr(exr, scenes.sky(128, 64), "zip")
+    assets.write_exr(exr, scenes.sky(128, 64), "piz", half=True)
     bn_png = Path(__file__).resolve().parent.parent / "resources" / "bluenoise.png"
     W, H, spp, bounces = 80, 60, 4, 3
     c = scenes.CORNELL_CAMERA
