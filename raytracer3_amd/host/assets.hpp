@@ -212,6 +212,7 @@ inline Image decode_png(const uint8_t* d, size_t n) {
         const uint8_t* body = d + p + 8;
         if (p + 12 + (size_t)len > n) throw std::runtime_error("PNG: truncated chunk");
         if (!std::memcmp(typ, "IHDR", 4)) {
+            if (len < 13) throw std::runtime_error("PNG: short IHDR");
             w = be32(body);
             h = be32(body + 4);
             depth = body[8];
@@ -224,6 +225,7 @@ inline Image decode_png(const uint8_t* d, size_t n) {
         p += 12 + (size_t)len;
     }
     if (!w || !h) throw std::runtime_error("PNG: no IHDR");
+    if (w > 32768u || h > 32768u) throw std::runtime_error("PNG: image larger than 32768 x 32768");
     if (interlace > 1) throw std::runtime_error("PNG: unknown interlace method");
     const int chans = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!chans || !(depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) throw std::runtime_error("PNG: bad colour type / depth");
@@ -242,6 +244,7 @@ inline Image decode_png(const uint8_t* d, size_t n) {
     }
     size_t want = 0;
     for (auto& ps : passes) want += (row_bytes(ps.pw) + 1) * ps.ph;
+    if (want > idat.size() * 1032 + 1024) throw std::runtime_error("PNG: IDAT is too short for the image size");  // deflate expands at most ~1032x
     std::vector<uint8_t> raw = inflate_all(idat.data(), idat.size(), want);
     if (raw.size() != want) throw std::runtime_error("PNG: wrong amount of image data");
     Image out;
@@ -367,6 +370,7 @@ class JpegDecoder {
             h.valptr[l] = k;
             h.mincode[l] = code;
             code += h.bits[l];
+            if (code > (1 << l)) fail("over-subscribed Huffman table");
             k += h.bits[l];
             h.maxcode[l] = h.bits[l] ? code - 1 : -1;
             code <<= 1;
@@ -392,9 +396,10 @@ class JpegDecoder {
         return (int)((bitbuf_ >> bitcnt_) & 1u);
     }
     int receive(int s) {
-        int v = 0;
-        for (int i = 0; i < s; i++) v = (v << 1) | getbit();
-        return v;
+        if (s > 16) fail("bad magnitude category");
+        uint32_t v = 0;
+        for (int i = 0; i < s; i++) v = (v << 1) | (uint32_t)getbit();
+        return (int)v;
     }
     static int extend(int v, int s) { return s && v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
     int decode_sym(const Huff& h) {
@@ -634,6 +639,8 @@ class JpegDecoder {
                 width_ = u16();
                 ncomp_ = u8();
                 if ((ncomp_ != 1 && ncomp_ != 3) || !width_ || !height_) fail("only 1- and 3-component images are supported");
+                if ((size_t)width_ * (size_t)height_ > ((size_t)1 << 28)) fail("image larger than 2^28 pixels");
+                if (p_ + 3 * (size_t)ncomp_ > end) fail("short frame header");
                 for (int i = 0; i < ncomp_; i++) {
                     comp_[i].id = u8();
                     const int hv = u8();
@@ -1275,14 +1282,21 @@ inline SkyImage read_exr(const std::string& path) {
     if (le32(0) != 20000630u) throw std::runtime_error(path + ": not an OpenEXR file");
     if (le32(4) & 0x200u) throw std::runtime_error(path + ": tiled EXR is not supported");
     size_t p = 8;
+    auto cstr = [&](size_t& q, size_t limit) -> std::string {  // NUL-terminated string inside [q, limit)
+        size_t e = q;
+        while (e < limit && d[e] != 0) e++;
+        if (e >= limit) throw std::runtime_error(path + ": unterminated string in the EXR header");
+        std::string r((const char*)&d[q], e - q);
+        q = e + 1;
+        return r;
+    };
     std::map<std::string, std::pair<size_t, size_t>> attrs;  // name -> (offset, length)
     while (p < d.size() && d[p] != 0) {
-        std::string name((const char*)&d[p]);
-        p += name.size() + 1;
-        std::string typ((const char*)&d[p]);
-        p += typ.size() + 1;
+        const std::string name = cstr(p, d.size());
+        cstr(p, d.size());  // the attribute's type name
         const uint32_t ln = le32(p);
         p += 4;
+        if (p + (size_t)ln > d.size()) throw std::runtime_error(path + ": EXR attribute exceeds the file");
         attrs[name] = {p, ln};
         p += ln;
     }
@@ -1295,14 +1309,17 @@ inline SkyImage read_exr(const std::string& path) {
     const uint32_t lines_per_block = comp == 3 ? 16u : (comp == 4 ? 32u : 1u);
     struct Chan { std::string name; int type; };
     std::vector<Chan> chans;
-    for (size_t q = attrs["channels"].first; d[q] != 0;) {
-        std::string nm((const char*)&d[q]);
-        q += nm.size() + 1;
+    if (attrs["compression"].second < 1 || attrs["dataWindow"].second < 16) throw std::runtime_error(path + ": short EXR attribute");
+    for (size_t q = attrs["channels"].first, qe = q + attrs["channels"].second; q < qe && d[q] != 0;) {
+        const std::string nm = cstr(q, qe);
+        if (q + 16 > qe) throw std::runtime_error(path + ": truncated EXR channel list");
         chans.push_back({nm, (int)le32(q)});
         q += 16;
     }
+    if (chans.empty() || chans.size() > 64) throw std::runtime_error(path + ": bad EXR channel list");
     const size_t dw = attrs["dataWindow"].first;
     const int32_t x0 = (int32_t)le32(dw), y0 = (int32_t)le32(dw + 4), x1 = (int32_t)le32(dw + 8), y1 = (int32_t)le32(dw + 12);
+    if (x1 < x0 || y1 < y0 || (int64_t)x1 - x0 >= 65536 || (int64_t)y1 - y0 >= 65536) throw std::runtime_error(path + ": bad EXR data window");
     SkyImage img;
     img.w = (uint32_t)(x1 - x0 + 1);
     img.h = (uint32_t)(y1 - y0 + 1);
@@ -1314,8 +1331,9 @@ inline SkyImage read_exr(const std::string& path) {
         const size_t o = (size_t)le64(p + 8 * (size_t)b);
         const int32_t y = (int32_t)le32(o);
         const uint32_t size = le32(o + 4);
+        if (y < y0 || y > y1) throw std::runtime_error(path + ": EXR block outside the data window");
         const uint32_t n_lines = std::min<uint32_t>(lines_per_block, (uint32_t)(y1 + 1 - y));
-        if (o + 8 + size > d.size()) throw std::runtime_error(path + ": EXR block exceeds the file");
+        if (o + 8 + (size_t)size > d.size()) throw std::runtime_error(path + ": EXR block exceeds the file");
         std::vector<uint8_t> block(d.begin() + (long)(o + 8), d.begin() + (long)(o + 8 + size));
         const size_t want = line_bytes * n_lines;
         if (comp == 4 && size < want) {  // a block that does not shrink is stored raw
@@ -1330,6 +1348,7 @@ inline SkyImage read_exr(const std::string& path) {
             const size_t half = (want + 1) / 2;
             for (size_t k = 0; k < want; k++) block[k] = (k & 1) ? t[half + k / 2] : t[k / 2];
         }
+        if (block.size() < want) throw std::runtime_error(path + ": EXR block is too short");
         size_t q = 0;
         for (uint32_t ly = 0; ly < n_lines; ly++)
             for (auto& c : chans) {
