@@ -1107,7 +1107,9 @@ static void traverse(const orc_scene *s, const float o[3], const float d[3], flo
                      hit_t *out, uint32_t *cn, uint32_t *ct) {
     hit_t best = {tmax, 0.0f, 0.0f, ORC_MISS};
     uint32_t nn = 0, nt = 0;
-    if (s->n_tris) {
+    int finite_ray = 1; /* [rule] a ray with a non-finite origin or direction misses (Vulkan leaves it undefined); same in the product */
+    for (int k = 0; k < 3; k++) finite_ray &= (fabsf(o[k]) <= 3.4028234663852886e38f) & (fabsf(d[k]) <= 3.4028234663852886e38f);
+    if (s->n_tris && finite_ray) {
         float inv[3] = {guard_inv(d[0]), guard_inv(d[1]), guard_inv(d[2])};
         uint32_t stack[ORC_STACK]; int sp = 0;
         uint32_t cur = 0;

@@ -182,7 +182,12 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
                 r.cn = r.ct = 0u;
                 busy = true;
                 if (MODE == 2) lane_any = second_pool;
-                if (nodes == nullptr) {  // empty scene: everything misses
+                // a ray with a non-finite origin or direction (NaN camera, a zero-length shading normal upstream) misses: with NaNs every
+                // slab test of the min/max form passes and the ray would walk the whole tree
+                const float kMaxF = 3.4028234663852886e38f;
+                const bool finite_ray = fabsf(r.o.x) <= kMaxF && fabsf(r.o.y) <= kMaxF && fabsf(r.o.z) <= kMaxF && fabsf(r.d.x) <= kMaxF &&
+                                        fabsf(r.d.y) <= kMaxF && fabsf(r.d.z) <= kMaxF;
+                if (nodes == nullptr || !finite_ray) {  // empty scene: everything misses
                     finish(r.index, r.best, 0u, 0u, MODE == 2 ? lane_any : MODE == 1, r.pay0, r.pay1);
                     busy = false;
                 }

@@ -699,3 +699,32 @@ def test_config_c5_progressive_accumulation_is_a_running_mean():
         f = np.float32(1.0 / (p + 1))
         want = want + (singles[p] - want) * f
     assert np.allclose(acc, want, rtol=2e-6, atol=1e-7) and np.abs(acc - np.mean(singles, 0)).max() < 1e-3 * max(1.0, float(acc.max()))
+
+
+def test_non_finite_rays_and_a_nan_camera(cornell):
+    """Non-finite rays miss at once on both sides of the ABI; a frame whose camera matrix holds a NaN therefore comes back
+    promptly with every pixel on the background instead of walking the whole tree two million times."""
+    mesh, osc = cornell
+    ctx = Context(0)
+    ctx.upload_mesh(mesh)
+    ctx.build_accel()
+    rays = rays_random(4096, 5, [-0.9, 0.1, -0.9], [0.9, 1.9, 0.9])
+    rng = np.random.default_rng(6)
+    idx = rng.choice(4096, 600, replace=False)
+    rays[rng.integers(0, 6, 600), idx] = rng.choice([np.nan, np.inf, -np.inf], 600)
+    t, u, v, p, cn, ct, _ = ctx.trace_rays(rays, counts=True)
+    ot, ou, ov, op, on, ont = osc.trace_closest(rays, counts=True)
+    assert np.array_equal(p, op) and np.array_equal(cn, on) and np.array_equal(ct, ont) and (p[idx] == L.MISS).all() and (cn[idx] == 0).all()
+    hit = p != L.MISS
+    assert hit.sum() > 3000 and np.array_equal(t[hit].view(np.uint32), ot[hit].view(np.uint32))
+    occ = ctx.trace_rays(rays, any_hit=True)[3]
+    assert np.array_equal(occ, osc.trace_any(rays)) and (occ[idx] == 0).all()
+    ctx.close()
+    pt = PathTracer((320, 200))
+    pt.set_scene(mesh)
+    cam = Camera(scenes.CORNELL_CAMERA["position"], scenes.CORNELL_CAMERA["direction"], math.radians(40.0), 1.6)
+    g = pt.make_gconst(cam, 4, 3, flags=0)
+    g.view_inverse[5] = float("nan")
+    pt.render(g)
+    assert (pt.gbuffer()[1] == L.BACKGROUND_DEPTH).all() and (pt.light() == 0).all()
+    pt.close()

@@ -96,3 +96,20 @@ def test_closed_box_does_not_leak_through_shared_edges():
     t, u, v, p = sc.trace_closest(rays)
     assert len(p) > 2000 and (p != orc.MISS).all()
     assert sc.trace_any(rays).all()
+
+
+def test_non_finite_rays_miss_without_walking_the_tree():
+    """[rule] NaN / Inf in a ray's origin or direction (a NaN camera, a zero-length normal upstream) = miss, zero visits: with NaNs
+    every min/max slab test passes and such a ray would otherwise visit every node and triangle."""
+    import orc
+    from raytracer3_amd import scenes
+    s = orc.Scene(scenes.cornell())
+    rays = np.tile(np.array([[0.0], [1.0], [3.0], [0.0], [0.0], [-1.0], [0.0], [1e5]], np.float32), (1, 8))
+    bad = [np.nan, np.inf, -np.inf]
+    for k in range(6):
+        rays[k, k + 1] = bad[k % 3]
+    t, u, v, p, nn, nt = s.trace_closest(rays, counts=True)
+    assert p[0] != orc.MISS and nn[0] > 0  # the untouched ray hits the back wall
+    assert (p[1:7] == orc.MISS).all() and (nn[1:7] == 0).all() and (nt[1:7] == 0).all() and p[7] == p[0]
+    occ, on, ot = s.trace_any(rays, counts=True)
+    assert occ[0] == 1 and (occ[1:7] == 0).all() and (on[1:7] == 0).all()
