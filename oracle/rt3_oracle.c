@@ -603,6 +603,8 @@ static float luminance3(const float c[3]) { return c[0] * 0.299f + c[1] * 0.587f
 /* [north_star] sky importance tables: f = luminance * sin(theta) per texel, conditional CDF per row, marginal CDF
  * over rows, pdf in (u,v) space.  Built in double, stored as float. */
 int orc_scene_set_sky(orc_scene *s, const float *rgb, uint32_t w, uint32_t h) {
+    for (size_t i = 0; i < (size_t)w * h * 3; i++) /* same contract as rt3_scene_set_sky: finite, non-negative radiance */
+        if (!(rgb[i] >= 0.0f && rgb[i] <= 3.4028234663852886e38f)) return -1;
     free(s->sky); free(s->cdf_cond); free(s->cdf_marg); free(s->pdf_uv);
     size_t n = (size_t)w * h;
     s->sky = (float *)malloc(n * 12);

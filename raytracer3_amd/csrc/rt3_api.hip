@@ -806,6 +806,9 @@ int rt3_scene_set_sky(rt3_ctx* c, const float* rgb, uint32_t w, uint32_t h) {
     if (w > 65535 || h > 65535) return fail(c, RT3_E_INVALID, "sky larger than 65535 texels per side");
     HIPC(c, hipSetDevice(c->device));
     const size_t n = (size_t)w * h;
+    for (size_t i = 0; i < 3 * n; i++)  // a NaN or negative texel would poison the sampling tables (every CDF entry after it)
+        if (!(rgb[i] >= 0.0f && rgb[i] <= 3.4028234663852886e38f))
+            return fail(c, RT3_E_INVALID, "sky texel " + std::to_string(i / 3) + " is negative or not finite (clamp the image before uploading it)");
     std::vector<float> cond(n), pdf(n), marg(h);
     std::vector<double> rows(h);
     double total = 0.0;

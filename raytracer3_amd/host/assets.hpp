@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -1475,6 +1476,20 @@ inline uint32_t upload(rt3_ctx* ctx, const Mesh& m) {
     check(ctx, rt3_accel_build(ctx, &handle), "rt3_accel_build");
     return handle;
 }
-inline void upload_sky(rt3_ctx* ctx, const SkyImage& s) { check(ctx, rt3_scene_set_sky(ctx, s.rgb.data(), s.w, s.h), "rt3_scene_set_sky"); }
+// rt3_scene_set_sky wants finite, non-negative radiance; HDR files do carry +inf sun texels, NaNs and slightly negative values, so
+// the upload helper clamps them (NaN -> 0, negative -> 0, inf -> HALF max) and says how many it touched
+inline size_t sanitize_sky(SkyImage& s) {
+    size_t touched = 0;
+    for (float& v : s.rgb)
+        if (!(v >= 0.0f && v <= 65504.0f)) {
+            v = v > 65504.0f ? 65504.0f : 0.0f;  // NaN compares false everywhere -> 0
+            touched++;
+        }
+    return touched;
+}
+inline void upload_sky(rt3_ctx* ctx, SkyImage s) {
+    if (const size_t n = sanitize_sky(s)) fprintf(stderr, "assets: clamped %zu sky values outside [0, 65504]\n", n);
+    check(ctx, rt3_scene_set_sky(ctx, s.rgb.data(), s.w, s.h), "rt3_scene_set_sky");
+}
 
 }  // namespace rt3::assets

@@ -402,6 +402,12 @@ def test_error_behaviour(small):
     assert lib.rt3_image_create(ctx.h, 64, 64, 12345, C.byref(img)) == L.E_INVALID
     assert lib.rt3_image_create(ctx.h, 64, 64, L.FORMAT_R32_SFLOAT, C.byref(img)) == 0
     assert img.value >> 30 == L.TAG_IMAGE
+    # sky radiance must be finite and non-negative (a NaN would poison every CDF entry after it); the oracle applies the same contract
+    for bad_value in (np.nan, np.inf, -1.0):
+        bad_sky = np.ones((4, 8, 3), np.float32)
+        bad_sky[2, 3, 1] = bad_value
+        assert lib.rt3_scene_set_sky(ctx.h, bad_sky.ctypes.data, 8, 4) == L.E_INVALID and b"sky texel 19" in lib.rt3_last_error(ctx.h)
+        assert orc.lib().orc_scene_set_sky(osc.h, orc.ptr(bad_sky), 8, 4) == -1
     # a geometry that references a texture nobody uploaded is refused at launch time, not dereferenced on the GPU
     gi = mesh.geometries.copy()
     gi["base_color_texture_index"][0] = 0

@@ -50,6 +50,8 @@ def main():
     else:
         mesh, cam_kw = scenes.atrium(args.detail), scenes.ATRIUM_CAMERA
     sky = assets.read_exr(args.exr) if args.exr else (scenes.sky(2048, 1024) if args.scene == "atrium" or args.glb else None)
+    if sky is not None:  # rt3_scene_set_sky wants finite, non-negative radiance; HDR files carry inf / NaN / tiny negatives
+        sky = np.clip(np.nan_to_num(sky, nan=0.0, posinf=65504.0, neginf=0.0), 0.0, 65504.0).astype(np.float32)
     flags = args.flags if args.flags >= 0 else (DEFAULT_FLAGS if sky is not None else L.F_FACEFORWARD | L.F_SPECULAR)
     pt = PathTracer((W, H))
     pt.set_scene(mesh, sky, assets.load_bluenoise())
