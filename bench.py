@@ -1,16 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the hot path (BASELINE.json: "Mrays/s + ms/frame, Sponza 1080p@64spp").
 
-A step = one frame: gbuffer pass + refrence_mode pass (B = 4, full estimator: diffuse BSDF + sky NEE/MIS +
-blue-noise shift) over this rank's 64x64 tiles, then ONE gather of the per-rank tile buffers to rank 0.
+A step = one frame: gbuffer pass + refrence_mode pass (B = 4, full estimator: layered BSDF + sky NEE/MIS + blue-noise shift)
+over this rank's 64x64 tiles, then the frame's ONE collective: rt3_gather_tiles (RCCL inside librt3, on librt3's stream).
 Workload = configs[2] (C3): atrium stand-in (sponza_scene.glb is not shipped), 1920x1080 @ 64 spp.
 value = Mrays/s = (primary + bounce + shadow rays of all ranks) / max-over-ranks frame time; ms_per_step = ms/frame.
 Strong scaling: the frame is fixed, tiles are split over the ranks.
 
+Launch: `python bench.py --gpus N` starts its N ranks itself (one child process per GPU, spawned BEFORE anything touches the
+GPU in the parent, which never imports torch or librt3), prints rank 0's JSON line and exits non-zero if a rank fails or if
+fewer than N devices are visible.  Under `torch.distributed.run` (WORLD_SIZE set) it is a rank.  RT3_DIST_BACKEND=gloo is a
+REHEARSAL for a one-GPU box: the ranks share the visible GPU(s) and the gather's bytes move through host tensors.
+
 Extra objects on the JSON line:
-  roofline     the dominant kernel -- k_extend (k_trace if --fused-trace 1: extension queue then shadow queue in one
-               launch): algorithmic bytes (48 + 64 n_nodes + 48 n_tris per ray) / HIP-event time of its
-               launches inside the timed region, against the 8 TB/s HBM3E peak
+  roofline     the dominant kernel (k_extend).  `achieved` / `frac` are MEASURED fabric-side bytes (rocprofv3 FETCH_SIZE /
+               WRITE_SIZE passes of this same command, committed under profiles/, quoted only while their kernel time agrees
+               with this run) over the live HIP-event launch time, against the 8 TB/s HBM3E peak -- a fraction that cannot
+               exceed 1.  The ALGORITHMIC bytes of SURVEY 8d (48 + node_bytes n_nodes + 48 n_tris per ray) are reported
+               beside it: the BVH is cache resident, so that figure is a cache-side gather rate, not HBM traffic, and is
+               priced against the measured L2 / Infinity-Cache gather rates instead.  `binding` says what the counters show
+               the kernel is limited by; `k_shade` carries the same for the one kernel that really is traffic bound.
   cpu_baseline the CPU oracle (a port; the reference cannot be built here) path tracing a centred crop of the same
                frame on the host cores; the crop also yields rmse_vs_oracle
 """
@@ -50,6 +59,82 @@ def usable_cpus() -> int:
     return max(1, min(n, 256))
 
 
+def visible_gpus() -> int:
+    """Devices a rank could open, counted in a short-lived CHILD: the launching parent must never initialise the GPU (a process
+    that did cannot hand over to other programs on this pool) -- it does not even import torch."""
+    import subprocess
+
+    r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=600)
+    try:
+        return int(r.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        return 0
+
+
+def self_launch(n: int, argv: list) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes, relay rank 0's JSON line."""
+    import socket
+    import subprocess
+
+    backend = os.environ.get("RT3_DIST_BACKEND", "nccl")
+    ndev = visible_gpus()
+    if ndev < 1:
+        print("bench.py: no GPU visible (librt3 has no CPU fallback)", file=sys.stderr)
+        return 3
+    if backend == "nccl" and ndev < n:
+        print(f"bench.py: --gpus {n} needs {n} visible devices, found {ndev} (RCCL cannot put two ranks on one GPU; "
+              f"RT3_DIST_BACKEND=gloo rehearses the N-rank path on fewer)", file=sys.stderr)
+        return 3
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's peer mappings need it on this driver
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    rc = 0
+    try:
+        pending = set(range(n))
+        lines = []
+        import threading
+
+        def pump():  # rank 0's stdout: keep everything, relay at the end
+            for ln in procs[0].stdout:
+                lines.append(ln)
+
+        th = threading.Thread(target=pump, daemon=True)
+        th.start()
+        while pending:
+            for r in list(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
+                    for q in pending:  # exact PIDs of our own children: they would wait in a collective for ever
+                        procs[q].terminate()
+            time.sleep(0.05)
+        th.join(timeout=5)
+        js = [ln for ln in lines if ln.startswith("{")]
+        for ln in lines:
+            if not ln.startswith("{"):
+                sys.stderr.write(ln)
+        if rc == 0 and not js:
+            print("bench.py: rank 0 printed no result line", file=sys.stderr)
+            rc = 1
+        if rc == 0:
+            print(js[-1].strip())
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,7 +157,11 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-crop", type=str, default="1280x720")  # ~14 s of oracle time on the GPU box's 16 host cores
     args = ap.parse_args()
-    default_workload = (args.gpus == 1 and (args.width, args.height, args.spp, args.bounces, args.detail) == (1920, 1080, 64, 4, 1.0)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))
+    default_workload = ((args.width, args.height, args.spp, args.bounces, args.detail) == (1920, 1080, 64, 4, 1.0)
                         and args.batch_spp == 0 and args.leaf_size == 0 and args.node_width == 0 and args.node_quant == -1
                         and args.refill == -1 and args.flags == -1 and args.pool_chunk == 0 and args.fused_trace == -1 and args.sah_top == -1)
 
@@ -82,13 +171,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     dist = None
     # RT3_DIST_BACKEND=gloo is a REHEARSAL mode for a 1-GPU box: several ranks share GPU 0 and the gather goes through
     # host tensors.  The real multi-GPU run uses nccl (= RCCL over xGMI), one GPU per rank.
     backend = os.environ.get("RT3_DIST_BACKEND", "nccl")
-    device_index = local_rank % max(torch.cuda.device_count(), 1)
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py: no GPU visible (librt3 has no CPU fallback)")
+    if world > 1 and backend == "nccl" and ndev < world:
+        raise SystemExit(f"bench.py: {world} ranks need {world} visible devices, found {ndev} (RT3_DIST_BACKEND=gloo rehearses on fewer)")
+    device_index = local_rank % ndev
     if world > 1:
         import torch.distributed as dist
 
@@ -109,7 +203,6 @@ def main():
     sky = scenes.sky(2048, 1024)
     bn = assets.load_bluenoise()
     pt = PathTracer((W, H), device=device_index if world > 1 else 0, rank=rank, n_ranks=world)
-    pt.host_staged_gather = world > 1 and backend != "nccl"
     if args.leaf_size:
         pt.ctx.set_option(L.OPT_LEAF_SIZE, args.leaf_size)
     if args.node_width:
@@ -125,20 +218,28 @@ def main():
     if args.fused_trace >= 0:
         pt.ctx.set_option(L.OPT_FUSED_TRACE, args.fused_trace)
     pt.set_scene(mesh, sky, bn)
+    if world > 1 and backend == "nccl":
+        # librt3's own RCCL communicator: rank 0's unique id travels through the process group's key-value store (the C ABI opens
+        # no sockets; a Rust host would carry the 128 bytes over whatever channel it has)
+        store = dist.distributed_c10d._get_default_store()
+        if rank == 0:
+            store.set("rt3_comm_unique_id", pt.ctx.comm_unique_id())
+        pt.init_comm(bytes(store.get("rt3_comm_unique_id")))
     if args.batch_spp:
         pt.ctx.set_option(L.OPT_BATCH_SPP, args.batch_spp)
     cam = Camera(scenes.ATRIUM_CAMERA["position"], scenes.ATRIUM_CAMERA["direction"], math.radians(scenes.ATRIUM_CAMERA["fov_deg"]), W / H)
 
     def barrier():
+        pt.ctx.wait()  # librt3's own stream (passes + the gather's send / receives)
         if dist is not None:
             dist.barrier()
-        pt.ctx.wait()
         torch.cuda.synchronize()
 
     def frame(i):
         g = pt.make_gconst(cam, args.spp, args.bounces, frame=i, flags=DEFAULT_FLAGS if args.flags < 0 else args.flags)
         pt.render(g, postprocess=False, wait=False)
-        return pt.gather_light(dist, torch, download=False) if world > 1 else None, g  # the frame is assembled in rank 0's HBM; no host copy in the timed region
+        # the frame is assembled in rank 0's HBM (its `Light` image); no host copy and, on RCCL, no host synchronisation in the timed region
+        return pt.gather_light(dist, torch, download=False) if world > 1 else None, g
 
     for i in range(args.warmup):
         frame(i)
@@ -186,36 +287,91 @@ def main():
         dom_ms, dom_launches = st.trace_ms / steps, st.trace_launches / steps
     else:
         dom_name, dom_rays, dom_bytes, dom_ms, dom_launches = "k_extend", float(cst.extension_rays), ext_bytes, st.extend_ms / steps, st.extend_launches / steps
-    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    algo_gbps = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     trav_ms = (st.trace_ms + st.extend_ms + st.shadow_ms) / steps  # every traversal launch of the frame
     peak = 8000.0
-    # HBM-side bytes per launch cannot be counted from inside this process: they come from separate
-    # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command (tools/profile_round.sh), corrected as
-    # MI355X_MICROARCH.md prescribes by tools/summarize_profile.py and committed under profiles/. Only quoted for the
-    # default workload they were collected on; null otherwise.
-    traffic, traffic_src = None, None
-    tfiles = sorted((ROOT / "profiles").glob("*_traffic.json"))
-    if tfiles and default_workload:
+    launches = max(dom_launches, 1)
+    avg_ms = dom_ms / launches
+    # ---- measured fabric-side traffic.  HBM-side bytes cannot be counted from inside this process: they come from separate
+    # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command (tools/profile_round.sh), summarised by
+    # tools/summarize_profile.py into profiles/*_traffic.json.  Quoted only for the default workload they were collected on AND
+    # only while the kernel's average duration in that profile agrees with this run's within 15 % (a stale profile is not evidence).
+    prof = None
+    tfiles = sorted((ROOT / "profiles").glob("r*_traffic.json"))
+    if tfiles and default_workload and world == 1:
         tj = json.loads(tfiles[-1].read_text())
-        kk = [v for k, v in tj["kernels"].items() if k.startswith(f"rt3::{dom_name}<false")]
-        if kk:
-            traffic = round(kk[0]["hbm_bytes_per_launch"])
-            traffic_src = f"profiles/{tfiles[-1].name}: {tj['correction']}"
+        tj["_file"] = f"profiles/{tfiles[-1].name}"
+        prof = tj
+
+    def prof_kernel(prefix):
+        if prof is None:
+            return None
+        kk = [v for k, v in prof["kernels"].items() if k.startswith(prefix)]
+        return kk[0] if kk else None
+
+    def hbm_side(entry, live_avg_ms):
+        """{traffic, traffic_raw, achieved GB/s, frac} from a profile entry, or Nones when absent / stale."""
+        if not entry or not entry.get("avg_ms") or live_avg_ms <= 0 or abs(entry["avg_ms"] / live_avg_ms - 1.0) > 0.15:
+            return {"traffic": None, "traffic_raw": None, "achieved": None, "frac": None, "stale_or_missing": True}
+        t = entry["hbm_bytes_per_launch"]
+        g = t / (live_avg_ms * 1e-3) / 1e9
+        return {"traffic": round(t), "traffic_raw": round(entry["fetch_bytes_raw"] + entry["write_bytes"]), "achieved": round(g, 1), "frac": round(g / peak, 4)}
+
+    ke = hbm_side(prof_kernel(f"rt3::{dom_name}<false"), avg_ms)
+    # what the kernel MUST move through HBM whatever the caches do: its ray records in and hit records out (the queues are 24 GB)
+    stream_bytes = 48.0 * dom_rays / launches
+    stream_gbps = stream_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    sq = prof_kernel(f"rt3::{dom_name}<false") or {}
+    binding = None
+    if sq.get("valu_per_clk_per_simd") is not None and not ke.get("stale_or_missing"):
+        # a wave64 VALU instruction holds its SIMD-32 for two cycles: the issue ceiling is 0.5 per clock per SIMD
+        binding = {"bound": "valu_issue+cache_latency", "achieved": sq["valu_per_clk_per_simd"], "peak": 0.5, "unit": "wave VALU instr / clk / SIMD",
+                   "frac": round(sq["valu_per_clk_per_simd"] / 0.5, 4), "wait_any": sq.get("wait_any"), "wait_inst_any": sq.get("wait_inst_any"),
+                   "active_inst_any": sq.get("active_inst_any"), "source": prof["_file"] if prof else None}
+    # ---- k_shade: the kernel that really is traffic bound.  Streaming bytes it must move per frame (record sizes of DESIGN.md 5):
+    # first bounce: {pixel, blue noise} 8 + depth 4 + G-buffer 16 in, radiance slot 16 out; later bounces: ray 32 + throughput/pdf 16 +
+    # path id 4 + hit 16 in; every extension ray out 52 (ray 32 + throughput/pdf 16 + path id 4), every shadow ray out 40
+    n_first_paths = float(W * H * args.spp) / world
+    later_in = max(float(cst.extension_rays) - float(W * H) / world, 0.0)  # every bounce ray traced is one path vertex shaded afterwards
+    shade_stream = n_first_paths * (28.0 + 16.0) + later_in * 68.0 + later_in * 52.0 + float(cst.shadow_rays) * 40.0
+    shade_ms = st.shade_ms / steps
+    shade_gbps = shade_stream / (shade_ms * 1e-3) / 1e9 if shade_ms > 0 else 0.0
+    sh_first, sh_later = prof_kernel("rt3::k_shade<true>"), prof_kernel("rt3::k_shade<false>")
+    shade_traffic = None
+    if sh_first and sh_later and sh_first.get("avg_ms") and sh_later.get("avg_ms"):
+        prof_shade_ms = sh_first["avg_ms"] + sh_later["avg_ms"] * (args.bounces - 1)
+        if shade_ms > 0 and abs(prof_shade_ms / shade_ms - 1.0) <= 0.15:
+            shade_traffic = sh_first["hbm_bytes_per_launch"] + sh_later["hbm_bytes_per_launch"] * (args.bounces - 1)
     roofline = {
-        "kernel": dom_name, "bound": "hbm", "achieved": round(achieved, 1), "peak": peak, "unit": "GB/s", "frac": round(achieved / peak, 4),
-        "frac_of_measured_copy_peak": round(achieved / 6290.0, 4),  # 6.29 TB/s float4 copy (MI355X_MICROARCH.md); SURVEY 8d asks for both
-        "traffic": traffic, "traffic_source": traffic_src,
-        "launches_per_frame": dom_launches, "avg_launch_ms": round(dom_ms / max(dom_launches, 1), 4),
-        "algorithmic_bytes_per_launch": round(dom_bytes / max(dom_launches, 1)), "rays_per_launch": round(dom_rays / max(dom_launches, 1)),
-        "bytes_per_ray_formula": f"48 + {node_bytes}*n_nodes + 48*n_tris", "bvh": {"nodes": n_nodes, "node_bytes": node_bytes, "tris": n_tris, "levels": levels},
+        "kernel": dom_name, "bound": "hbm", "peak": peak, "unit": "GB/s",
+        # measured HBM-side (fabric) bytes of one launch / its live duration: the fraction of the HBM roofline the kernel occupies
+        "achieved": ke["achieved"] if ke["achieved"] is not None else round(stream_gbps, 1),
+        "frac": ke["frac"] if ke["frac"] is not None else round(stream_gbps / peak, 4),
+        "achieved_is": ("counter traffic (2 x FETCH_SIZE for 16 B/lane streaming reads, validated for 64 B gathers by profiles/r02_fetch_calibration.md) / live launch time"
+                        if ke["achieved"] is not None else "LOWER BOUND: compulsory queue bytes only (48 B per ray); no current counter profile for this workload"),
+        "traffic": ke["traffic"], "traffic_uncorrected": ke["traffic_raw"], "traffic_source": prof["_file"] if (prof and ke["traffic"] is not None) else None,
+        "compulsory_stream": {"bytes_per_launch": round(stream_bytes), "GBps": round(stream_gbps, 1), "frac": round(stream_gbps / peak, 4)},
+        # SURVEY 8d's contract figure.  NOT an HBM fraction: the 17 MB BVH is L2 / Infinity-Cache resident, so these bytes are cache-side
+        # gathers; the comparable ceilings are the measured gather rates (MI355X_MICROARCH.md: 8.6 TB/s from the Infinity Cache,
+        # 16.8-18.8 TB/s from L2), not the 8 TB/s of HBM
+        "algorithmic": {"bytes_per_launch": round(dom_bytes / launches), "GBps": round(algo_gbps, 1), "over_hbm_peak": round(algo_gbps / peak, 4),
+                        "frac_of_l2_gather_peak": round(algo_gbps / 17800.0, 4), "over_infinity_cache_gather_peak": round(algo_gbps / 8600.0, 4),
+                        "bytes_per_ray_formula": f"48 + {node_bytes}*n_nodes + 48*n_tris"},
+        "binding": binding,
+        "launches_per_frame": dom_launches, "avg_launch_ms": round(avg_ms, 4), "rays_per_launch": round(dom_rays / launches),
+        "bvh": {"nodes": n_nodes, "node_bytes": node_bytes, "tris": n_tris, "levels": levels},
         "rays_per_frame": int(cst.extension_rays), "nodes_per_ray": round(cst.nodes_visited / max(cst.extension_rays, 1), 2),
         "tris_per_ray": round(cst.tris_tested / max(cst.extension_rays, 1), 2),
         "shadow": {"rays_per_frame": int(cst.shadow_rays), "nodes_per_ray": round(cst.shadow_nodes_visited / max(cst.shadow_rays, 1), 2),
                    "tris_per_ray": round(cst.shadow_tris_tested / max(cst.shadow_rays, 1), 2)},
-        "all_traversal": {"achieved": round((ext_bytes + sh_bytes) / max(trav_ms * 1e-3, 1e-12) / 1e9, 1), "ms_per_frame": round(trav_ms, 3),
+        "all_traversal": {"algorithmic_GBps": round((ext_bytes + sh_bytes) / max(trav_ms * 1e-3, 1e-12) / 1e9, 1), "ms_per_frame": round(trav_ms, 3),
                           "launches_per_frame": (st.trace_launches + st.extend_launches + st.shadow_launches) / steps},
+        "k_shade": {"bound": "hbm", "streaming_bytes_per_frame": round(shade_stream), "achieved": round(shade_gbps, 1), "peak": peak, "unit": "GB/s",
+                    "frac": round(shade_gbps / peak, 4), "traffic_per_frame": round(shade_traffic) if shade_traffic else None,
+                    "hbm_side_frac": round(shade_traffic / (shade_ms * 1e-3) / 1e9 / peak, 4) if shade_traffic else None,
+                    "traffic_over_streaming": round(shade_traffic / shade_stream, 2) if shade_traffic else None},
         "ms_per_frame": {"k_trace": round(st.trace_ms / steps, 3), "k_extend": round(st.extend_ms / steps, 3), "k_shadow": round(st.shadow_ms / steps, 3),
-                         "k_shade": round(st.shade_ms / steps, 3), "other": round(st.other_ms / steps, 3)},
+                         "k_shade": round(st.shade_ms / steps, 3), "gather": round(st.gather_ms / steps, 3), "other": round(st.other_ms / steps, 3)},
     }
 
     out = {
@@ -223,7 +379,7 @@ def main():
         "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"C3: atrium stand-in ({mesh.n_triangles} tris) {W}x{H}@{args.spp}spp B={args.bounces} layered BSDF (diffuse + GGX) + sky NEE/MIS + bluenoise, "
-                               f"64x64 tiles over {world} GPU(s), one gather", "rays_per_frame": int(rays_total / max(args.steps, 1)),
+                               f"64x64 tiles over {world} GPU(s), one gather", "rays_per_frame": int(rays_total / max(args.steps, 1)), "gather": ("none" if world == 1 else ("rt3_gather_tiles (RCCL)" if backend == "nccl" else "REHEARSAL: host-moved bytes (gloo), ranks share GPUs")),
                    "extension_rays_per_frame": int(ext_total / max(args.steps, 1)), "shadow_rays_per_frame": int(sh_total / max(args.steps, 1)),
                    "device": pt.ctx.device_name},
         "roofline": roofline,

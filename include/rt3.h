@@ -8,7 +8,8 @@
  *  - every call returns 0 on success or a negative RT3_E_* code; rt3_last_error() gives the text; nothing aborts or
  *    throws across the ABI (the reference `.unwrap()`s on its frame path, render_graph/mod.rs:601-610);
  *  - a context is NOT re-entrant: call it from one thread at a time (the reference's renderer systems are chained on
- *    the main thread, renderer/mod.rs:108-116); one context drives one GPU on one HIP stream;
+ *    the main thread, renderer/mod.rs:108-116); one context drives one GPU on one HIP stream (multi-GPU: one context
+ *    and one process per GPU, joined only by rt3_gather_tiles);
  *  - host pointers are borrowed for the duration of the call and copied synchronously (like DynamicBuffer::push,
  *    vulkan/buffer.rs:406-420); device memory is owned by the context and released by rt3_destroy();
  *  - resource handles are u32 `tag << 30 | index` exactly like DescriptorResourceHandle (bindless/mod.rs:67-77):
@@ -30,6 +31,7 @@ extern "C" {
 #define RT3_E_STATE (-4)       /* call order (e.g. pass launched before rt3_accel_build) */
 #define RT3_E_UNSUPPORTED (-5) /* a feature this build does not implement */
 #define RT3_E_DEPTH (-6)       /* BVH deeper than the traversal stack supports */
+#define RT3_E_COMM (-7)        /* an RCCL call of the frame-end gather failed (text in rt3_last_error) */
 
 #define RT3_INVALID_HANDLE 0xFFFFFFFFu
 #define RT3_TAG_BUFFER 0u
@@ -104,6 +106,7 @@ typedef struct rt3_stats {
     uint64_t trace_rays[2];  /* counting mode: [0] closest-hit, [1] any-hit rays traced by k_trace launches */
     uint64_t trace_nodes[2];
     uint64_t trace_tris[2];
+    double gather_ms; /* RCCL send / grouped receives of rt3_gather_tiles (the pack / untile kernels are in other_ms) */
 } rt3_stats;
 
 typedef struct rt3_ctx rt3_ctx;
@@ -164,6 +167,26 @@ int rt3_tile_pixel_count(rt3_ctx *ctx, uint32_t rank, uint32_t n_ranks, uint32_t
 /* gather support: image (full window) <-> contiguous per-rank tile buffer (count x 16 bytes, device memory) */
 int rt3_image_pack_tiles(rt3_ctx *ctx, uint32_t image, uint32_t rank, uint32_t n_ranks, void *dst_device);
 int rt3_image_unpack_tiles(rt3_ctx *ctx, uint32_t image, uint32_t rank, uint32_t n_ranks, const void *src_device);
+
+/* ---- frame-end gather (north_star: "the framebuffer is tile-partitioned across the 8 GPUs of one node with a single RCCL gather
+ *      over xGMI at frame end").  No reference counterpart: the reference is single-device.  One context =
+ *      one rank = one GPU = one process.  Rank 0 makes an id with rt3_comm_unique_id and the HOST carries its 128 bytes to the
+ *      other ranks over whatever channel it already has (the ABI opens no sockets); then every rank calls rt3_comm_init
+ *      (collective: ncclCommInitRank on the context's device) with the rank / n_ranks it gave rt3_set_tile_partition.
+ *      rt3_gather_tiles is the one collective of a frame: enqueued on the context's stream behind the passes, no host
+ *      synchronisation.  Non-root ranks pack their tiles of `image` and send them; `root` receives every rank's tiles at its exact
+ *      offset of ONE contiguous buffer (all receives in one RCCL group: the root's inbound xGMI links run concurrently, nothing is
+ *      forwarded) and scatters them into its `image` with ONE untile launch.  The root's own tiles never move.
+ *      rt3_gather_layout / rt3_gather_unpack expose the root's half without the exchange (hosts that move the bytes themselves --
+ *      the gloo rehearsal on a one-GPU box -- and the layout tests): offsets[r] .. offsets[r+1] is rank r's pixel range in the
+ *      receive buffer (16 bytes per pixel, pixels in rt3_image_pack_tiles order, the root's range empty), n_ranks + 1 entries. ---- */
+#define RT3_COMM_ID_BYTES 128
+int rt3_comm_unique_id(void *id_out /* RT3_COMM_ID_BYTES */);
+int rt3_comm_init(rt3_ctx *ctx, const void *id /* RT3_COMM_ID_BYTES */, uint32_t rank, uint32_t n_ranks);
+int rt3_comm_destroy(rt3_ctx *ctx);
+int rt3_gather_tiles(rt3_ctx *ctx, uint32_t image, uint32_t root);
+int rt3_gather_layout(rt3_ctx *ctx, uint32_t image, uint32_t root, uint32_t n_ranks, uint64_t *offsets /* n_ranks + 1 */);
+int rt3_gather_unpack(rt3_ctx *ctx, uint32_t image, uint32_t root, uint32_t n_ranks, const void *recv_device);
 
 /* ---- pass launch: ExecutionTrait::execute (render_graph/mod.rs:80-91) of a RayTracingPass / ComputePass node
  *      (render_graph/executions.rs:15-55,80-121) -> RayTracingPipelineHandle::launch(x, y) /

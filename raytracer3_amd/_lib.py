@@ -10,7 +10,8 @@ PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("RT3_LIBRARY", PKG / "librt3.so"))  # RT3_LIBRARY: another build of the same ABI (kernel experiments)
 
 RT3_OK = 0
-E_INVALID, E_HIP, E_NO_DEVICE, E_STATE, E_UNSUPPORTED, E_DEPTH = -1, -2, -3, -4, -5, -6
+E_INVALID, E_HIP, E_NO_DEVICE, E_STATE, E_UNSUPPORTED, E_DEPTH, E_COMM = -1, -2, -3, -4, -5, -6, -7
+COMM_ID_BYTES = 128
 TAG_BUFFER, TAG_IMAGE, TAG_ACCEL = 0, 1, 3
 MISS = 0xFFFFFFFF
 BACKGROUND_DEPTH = 100000.0
@@ -25,6 +26,7 @@ EXPORTS = [
     "rt3_accel_build", "rt3_accel_info", "rt3_accel_download", "rt3_sky_download",
     "rt3_buffer_create", "rt3_image_create", "rt3_image_import", "rt3_resource_upload", "rt3_resource_download", "rt3_resource_device_ptr",
     "rt3_set_tile_partition", "rt3_tile_pixel_count", "rt3_image_pack_tiles", "rt3_image_unpack_tiles",
+    "rt3_comm_unique_id", "rt3_comm_init", "rt3_comm_destroy", "rt3_gather_tiles", "rt3_gather_layout", "rt3_gather_unpack",
     "rt3_pass_launch", "rt3_frame_wait", "rt3_trace_rays", "rt3_selftest_eval", "rt3_stats_reset", "rt3_stats_get", "rt3_camera_gconst",
 ]
 
@@ -43,7 +45,7 @@ class Stats(C.Structure):
                 ("extend_launches", C.c_uint64), ("extend_ms", C.c_double), ("shadow_launches", C.c_uint64), ("shadow_ms", C.c_double),
                 ("shade_ms", C.c_double), ("other_ms", C.c_double),
                 ("trace_launches", C.c_uint64), ("trace_ms", C.c_double), ("trace_rays", C.c_uint64 * 2), ("trace_nodes", C.c_uint64 * 2),
-                ("trace_tris", C.c_uint64 * 2)]
+                ("trace_tris", C.c_uint64 * 2), ("gather_ms", C.c_double)]
 
 
 assert C.sizeof(GConst) == 304
@@ -101,6 +103,12 @@ def load():
         "rt3_tile_pixel_count": (i32, [vp, u32, u32, pu32]),
         "rt3_image_pack_tiles": (i32, [vp, u32, u32, u32, vp]),
         "rt3_image_unpack_tiles": (i32, [vp, u32, u32, u32, vp]),
+        "rt3_comm_unique_id": (i32, [vp]),
+        "rt3_comm_init": (i32, [vp, vp, u32, u32]),
+        "rt3_comm_destroy": (i32, [vp]),
+        "rt3_gather_tiles": (i32, [vp, u32, u32]),
+        "rt3_gather_layout": (i32, [vp, u32, u32, u32, C.POINTER(C.c_uint64)]),
+        "rt3_gather_unpack": (i32, [vp, u32, u32, u32, vp]),
         "rt3_pass_launch": (i32, [vp, C.c_char_p, C.c_char_p, u32, u32, u32, vp, sz, pu32, u32]),
         "rt3_frame_wait": (i32, [vp]),
         "rt3_trace_rays": (i32, [vp, vp, u32, i32, vp, vp, vp, vp, vp, vp, i32, C.POINTER(C.c_double)]),

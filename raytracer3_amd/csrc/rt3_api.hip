@@ -5,6 +5,7 @@
 // wavefront work queues.  rt3_pass_launch() is the drop-in for executing one pass node of the reference's frame graph
 // (render_graph/mod.rs:80-107): the pass name selects a HIP kernel sequence instead of a SPIR-V pipeline.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <cmath>
 #include <cstdio>
@@ -38,7 +39,16 @@ struct PixelList {
     uint2* dev_bn = nullptr;      // {x | y << 16, blue-noise word of that pixel}: one load instead of two dependent ones in k_shade
     uint64_t bn_stamp = ~0ull;    // which blue-noise upload dev_bn was built from
 };
-enum Cat { CAT_EXTEND = 0, CAT_SHADOW = 1, CAT_SHADE = 2, CAT_OTHER = 3, CAT_TRACE = 4 };
+// Frame-end gather (north_star: "a single RCCL gather over xGMI at frame end").  The root receives every other rank's tiles
+// into ONE contiguous buffer -- rank r's count[r] pixels at pixel offset off[r], ranks in ascending order, the root itself
+// contributing nothing (its tiles are already in its image) -- and scatters all of them with ONE untile launch over `dev`,
+// the concatenation of those ranks' pixel lists.
+struct GatherLayout {
+    uint32_t w, h, root, n_ranks;
+    std::vector<uint64_t> off;  // n_ranks + 1 entries, in pixels
+    uint32_t* dev = nullptr;    // off[n_ranks] pixel words (x | y << 16)
+};
+enum Cat { CAT_EXTEND = 0, CAT_SHADOW = 1, CAT_SHADE = 2, CAT_OTHER = 3, CAT_TRACE = 4, CAT_GATHER = 5 };
 struct Timed {
     hipEvent_t a, b;
     int cat;
@@ -77,12 +87,20 @@ struct rt3_ctx {
     bool tex_dirty = false;
     LbvhResult bvh;
     bool accel_built = false;
-    std::vector<uint32_t> h_indices;  // host copy, only for range validation in rt3_scene_set_geometry
+    std::vector<uint32_t> h_indices;  // host copies, only for range validation (rt3_scene_set_geometry, again in rt3_accel_build)
+    std::vector<rt3_geometry_info> h_geoms;
+    std::vector<uint32_t> h_prim_counts;
     int64_t max_tex_index = -1;
     // resources
     std::vector<Resource> resources;
     std::vector<PixelList> pixlists;
+    std::vector<GatherLayout> gather_layouts;
     uint32_t rank = 0, n_ranks = 1, part_w = 0, part_h = 0;
+    // communicator of the frame-end gather (RCCL): one rank per context / GPU / process
+    ncclComm_t comm = nullptr;
+    uint32_t comm_rank = 0, comm_size = 0;
+    void* gather_buf = nullptr;  // non-root: this rank's packed tiles; root: the receive buffer of all other ranks' tiles
+    size_t gather_buf_bytes = 0;
     // work queues (capacity in paths)
     size_t cap = 0, cap_pix = 0;
     float *rays[2] = {nullptr, nullptr}, *hits = nullptr, *T[2] = {nullptr, nullptr};
@@ -254,25 +272,37 @@ int sync_textures(rt3_ctx* c) {
     return RT3_OK;
 }
 
+// Failure-atomic: if any allocation fails the whole queue set is released and the capacities drop to 0, so the next pass
+// re-allocates (or reports the error again) instead of launching kernels on a half-resized set.
+void free_work(rt3_ctx* c) {
+    for (int k = 0; k < 2; k++) { dev_free(c->rays[k]); dev_free(c->T[k]); dev_free(c->pid[k]); }
+    dev_free(c->hits); dev_free(c->sh_rays); dev_free(c->sh_contrib); dev_free(c->lacc); dev_free(c->radsum);
+    c->cap = 0;
+    c->cap_pix = 0;
+}
 int ensure_work(rt3_ctx* c, size_t paths, size_t npix) {
+    int r = RT3_OK;
     if (paths > c->cap) {
         size_t P = (paths + 255) & ~(size_t)255;
-        for (int k = 0; k < 2; k++) {
-            if (int r = dev_alloc(c, &c->rays[k], 8 * P)) return r;
-            if (int r = dev_alloc(c, &c->T[k], 4 * P)) return r;
-            if (int r = dev_alloc(c, &c->pid[k], P)) return r;
+        c->cap = 0;
+        for (int k = 0; k < 2 && !r; k++) {
+            if (!r) r = dev_alloc(c, &c->rays[k], 8 * P);
+            if (!r) r = dev_alloc(c, &c->T[k], 4 * P);
+            if (!r) r = dev_alloc(c, &c->pid[k], P);
         }
-        if (int r = dev_alloc(c, &c->hits, 4 * P)) return r;
-        if (int r = dev_alloc(c, &c->sh_rays, 8 * P)) return r;
-        if (int r = dev_alloc(c, &c->sh_contrib, 2 * P)) return r;  // {blue contribution, path id} records (red / green ride with the ray)
-        if (int r = dev_alloc(c, &c->lacc, 4 * P)) return r;  // float4 per path
-        c->cap = P;
+        if (!r) r = dev_alloc(c, &c->hits, 4 * P);
+        if (!r) r = dev_alloc(c, &c->sh_rays, 8 * P);
+        if (!r) r = dev_alloc(c, &c->sh_contrib, 2 * P);  // {blue contribution, path id} records (red / green ride with the ray)
+        if (!r) r = dev_alloc(c, &c->lacc, 4 * P);        // float4 per path
+        if (!r) c->cap = P;
     }
-    if (npix > c->cap_pix) {
-        if (int r = dev_alloc(c, &c->radsum, 3 * npix)) return r;
-        c->cap_pix = npix;
+    if (!r && npix > c->cap_pix) {
+        c->cap_pix = 0;
+        r = dev_alloc(c, &c->radsum, 3 * npix);
+        if (!r) c->cap_pix = npix;
     }
-    return RT3_OK;
+    if (r) free_work(c);
+    return r;
 }
 
 int harvest(rt3_ctx* c) {  // stream must be idle
@@ -313,6 +343,7 @@ int harvest(rt3_ctx* c) {  // stream must be idle
             case CAT_SHADOW: c->stats.shadow_ms += ms; c->stats.shadow_launches++; break;
             case CAT_SHADE: c->stats.shade_ms += ms; break;
             case CAT_TRACE: c->stats.trace_ms += ms; c->stats.trace_launches++; break;
+            case CAT_GATHER: c->stats.gather_ms += ms; break;
             default: c->stats.other_ms += ms; break;
         }
         c->free_events.push_back(t);
@@ -668,8 +699,10 @@ void rt3_destroy(rt3_ctx* c) {
         (void)hipFree(p.dev);
         (void)hipFree(p.dev_bn);
     }
-    for (int k = 0; k < 2; k++) { dev_free(c->rays[k]); dev_free(c->T[k]); dev_free(c->pid[k]); }
-    dev_free(c->hits); dev_free(c->sh_rays); dev_free(c->sh_contrib); dev_free(c->lacc); dev_free(c->radsum);
+    free_work(c);
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    dev_free(c->gather_buf);
+    for (auto& gl : c->gather_layouts) (void)hipFree(gl.dev);
     dev_free(c->d_counters); dev_free(c->d_totals);
     for (auto& t : c->pending_events) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
     for (auto& t : c->free_events) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
@@ -761,23 +794,32 @@ int rt3_scene_set_indices(rt3_ctx* c, const uint32_t* idx, uint32_t n) {
     c->accel_built = false;
     return RT3_OK;
 }
-int rt3_scene_set_geometry(rt3_ctx* c, const rt3_geometry_info* g, const uint32_t* prim_counts, uint32_t n) {
-    if (!c || ((!g || !prim_counts) && n)) return fail(c, RT3_E_INVALID, "geometry NULL");
-    HIPC(c, hipSetDevice(c->device));
-    std::vector<uint32_t> first(n ? n : 1), pg;
-    uint64_t total = 0;
-    int64_t max_tex = -1;
+// bounds of every geometry's index / vertex range against the world buffers as they are NOW: the kernels index them without
+// checks (a GPU fault would take the node down).  Run by rt3_scene_set_geometry and again by rt3_accel_build, because the vertex
+// and index buffers may be replaced (by smaller ones) after the geometry was set.
+static int validate_geometry(rt3_ctx* c, const rt3_geometry_info* g, const uint32_t* prim_counts, uint32_t n) {
     for (uint32_t i = 0; i < n; i++) {
-        if (g[i].base_color_texture_index > max_tex) max_tex = g[i].base_color_texture_index;
-        // bounds: the kernels index the world buffers without checks (a GPU fault would take the node down)
-        if ((uint64_t)g[i].index_offset + 3ull * prim_counts[i] > c->n_indices) return fail(c, RT3_E_INVALID, "geometry index range exceeds the index buffer");
+        if ((uint64_t)g[i].index_offset + 3ull * prim_counts[i] > c->n_indices)
+            return fail(c, RT3_E_INVALID, "geometry " + std::to_string(i) + ": index range exceeds the index buffer");
         uint32_t mx = 0;
         for (uint64_t k = 0; k < 3ull * prim_counts[i]; k++) {
             uint32_t v = c->h_indices[g[i].index_offset + k];
             mx = v > mx ? v : mx;
         }
         if (prim_counts[i] && (uint64_t)g[i].vertex_offset + mx >= (uint64_t)c->n_verts)
-            return fail(c, RT3_E_INVALID, "geometry vertex range exceeds the vertex buffer (set vertices and indices before geometry)");
+            return fail(c, RT3_E_INVALID, "geometry " + std::to_string(i) + ": vertex range exceeds the vertex buffer (set vertices and indices before geometry)");
+    }
+    return RT3_OK;
+}
+int rt3_scene_set_geometry(rt3_ctx* c, const rt3_geometry_info* g, const uint32_t* prim_counts, uint32_t n) {
+    if (!c || ((!g || !prim_counts) && n)) return fail(c, RT3_E_INVALID, "geometry NULL");
+    HIPC(c, hipSetDevice(c->device));
+    if (int r = validate_geometry(c, g, prim_counts, n)) return r;
+    std::vector<uint32_t> first(n ? n : 1), pg;
+    uint64_t total = 0;
+    int64_t max_tex = -1;
+    for (uint32_t i = 0; i < n; i++) {
+        if (g[i].base_color_texture_index > max_tex) max_tex = g[i].base_color_texture_index;
         first[i] = (uint32_t)total;
         total += prim_counts[i];
     }
@@ -793,6 +835,8 @@ int rt3_scene_set_geometry(rt3_ctx* c, const rt3_geometry_info* g, const uint32_
         HIPC(c, hipMemcpy(c->d_first_prim, first.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     }
     if (total) HIPC(c, hipMemcpy(c->d_prim_geom, pg.data(), (size_t)total * 4, hipMemcpyHostToDevice));
+    c->h_geoms.assign(g, g + n);
+    c->h_prim_counts.assign(prim_counts, prim_counts + n);
     c->n_geoms = n;
     c->max_tex_index = max_tex;
     c->n_prims = (uint32_t)total;
@@ -936,6 +980,8 @@ int rt3_accel_build(rt3_ctx* c, uint32_t* out_handle) {
     HIPC(c, hipSetDevice(c->device));
     if (c->n_prims && (!c->d_verts || !c->d_indices)) return fail(c, RT3_E_STATE, "set vertices, indices and geometry before rt3_accel_build");
     if (c->n_prims > (1u << 28)) return fail(c, RT3_E_UNSUPPORTED, "more than 2^28 triangles (leaf references hold 28 bits)");
+    // the vertex / index buffers may have been replaced since rt3_scene_set_geometry checked its ranges against them
+    if (int r = validate_geometry(c, c->h_geoms.data(), c->h_prim_counts.data(), (uint32_t)c->h_geoms.size())) return r;
     HIPC(c, hipStreamSynchronize(c->stream));
     dev_free(c->bvh.nodes);
     dev_free(c->bvh.tris);
@@ -1086,6 +1132,155 @@ int rt3_image_unpack_tiles(rt3_ctx* c, uint32_t image, uint32_t rank, uint32_t n
     PixelList* pl;
     if (int e = get_pixlist(c, r->w, r->h, rank, n_ranks, &pl)) return e;
     if (pl->count) launch_unpack_tiles(c->stream, pl->dev, pl->count, r->w, src, r->ptr);
+    HIPC(c, hipGetLastError());
+    return RT3_OK;
+}
+
+// ---- frame-end gather over RCCL (north_star).  One rank per context: ncclCommInitRank from a unique id the host
+//      application carries from rank 0 to the others over whatever channel it has (the ABI never opens a socket itself).
+#define NCCLC(ctx, call)                                                                                          \
+    do {                                                                                                          \
+        ncclResult_t e_ = (call);                                                                                 \
+        if (e_ != ncclSuccess) return fail(ctx, RT3_E_COMM, std::string(#call) + ": " + ncclGetErrorString(e_));  \
+    } while (0)
+static_assert(sizeof(ncclUniqueId) == RT3_COMM_ID_BYTES, "RT3_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
+
+static int get_gather_layout(rt3_ctx* c, uint32_t w, uint32_t h, uint32_t root, uint32_t n_ranks, GatherLayout** out) {
+    for (auto& g : c->gather_layouts)
+        if (g.w == w && g.h == h && g.root == root && g.n_ranks == n_ranks) {
+            *out = &g;
+            return RT3_OK;
+        }
+    if (w == 0 || h == 0 || w > 65535 || h > 65535 || n_ranks == 0 || root >= n_ranks) return fail(c, RT3_E_INVALID, "bad window / root / rank count for the gather");
+    GatherLayout gl;
+    gl.w = w; gl.h = h; gl.root = root; gl.n_ranks = n_ranks;
+    gl.off.assign((size_t)n_ranks + 1, 0);
+    std::vector<uint32_t> all, px;
+    for (uint32_t r = 0; r < n_ranks; r++) {
+        gl.off[r] = all.size();
+        if (r == root) continue;  // the root's tiles never leave its image
+        tile_pixels(w, h, r, n_ranks, px);
+        all.insert(all.end(), px.begin(), px.end());
+    }
+    gl.off[n_ranks] = all.size();
+    HIPC(c, hipMalloc((void**)&gl.dev, (all.size() ? all.size() : 1) * 4));
+    if (!all.empty()) HIPC(c, hipMemcpy(gl.dev, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+    c->gather_layouts.push_back(gl);
+    *out = &c->gather_layouts.back();
+    return RT3_OK;
+}
+static int ensure_gather_buf(rt3_ctx* c, size_t bytes) {
+    if (bytes <= c->gather_buf_bytes) return RT3_OK;
+    HIPC(c, hipStreamSynchronize(c->stream));  // an earlier gather may still be reading the old buffer
+    dev_free(c->gather_buf);
+    c->gather_buf_bytes = 0;
+    HIPC(c, hipMalloc(&c->gather_buf, bytes));
+    c->gather_buf_bytes = bytes;
+    return RT3_OK;
+}
+
+int rt3_comm_unique_id(void* id_out) {
+    if (!id_out) return fail(nullptr, RT3_E_INVALID, "id_out is NULL");
+    ncclUniqueId id;
+    ncclResult_t e = ncclGetUniqueId(&id);
+    if (e != ncclSuccess) return fail(nullptr, RT3_E_COMM, std::string("ncclGetUniqueId: ") + ncclGetErrorString(e));
+    memcpy(id_out, &id, sizeof(id));
+    return RT3_OK;
+}
+int rt3_comm_init(rt3_ctx* c, const void* id, uint32_t rank, uint32_t n_ranks) {
+    if (!c || !id) return fail(c, RT3_E_INVALID, "comm_init: NULL argument");
+    if (n_ranks == 0 || rank >= n_ranks) return fail(c, RT3_E_INVALID, "comm_init: rank must be < n_ranks");
+    if (c->comm) return fail(c, RT3_E_STATE, "comm_init: this context already has a communicator (rt3_comm_destroy first)");
+    HIPC(c, hipSetDevice(c->device));
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    NCCLC(c, ncclCommInitRank(&c->comm, (int)n_ranks, uid, (int)rank));
+    c->comm_rank = rank;
+    c->comm_size = n_ranks;
+    return RT3_OK;
+}
+int rt3_comm_destroy(rt3_ctx* c) {
+    if (!c) return RT3_E_INVALID;
+    if (!c->comm) return RT3_OK;
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    ncclComm_t comm = c->comm;
+    c->comm = nullptr;
+    c->comm_size = 0;
+    NCCLC(c, ncclCommDestroy(comm));
+    return RT3_OK;
+}
+int rt3_gather_layout(rt3_ctx* c, uint32_t image, uint32_t root, uint32_t n_ranks, uint64_t* offsets) {
+    if (!c || !offsets) return fail(c, RT3_E_INVALID, "gather_layout: NULL argument");
+    Resource* r = get_res(c, image, RT3_TAG_IMAGE);
+    if (!r || format_bytes(r->format) != 16) return fail(c, RT3_E_INVALID, "the gather needs a 16-byte-per-pixel image");
+    HIPC(c, hipSetDevice(c->device));
+    GatherLayout* gl;
+    if (int e = get_gather_layout(c, r->w, r->h, root, n_ranks, &gl)) return e;
+    memcpy(offsets, gl->off.data(), ((size_t)n_ranks + 1) * sizeof(uint64_t));
+    return RT3_OK;
+}
+// the root's half of the gather without the exchange: `recv_device` is laid out as rt3_gather_layout says
+int rt3_gather_unpack(rt3_ctx* c, uint32_t image, uint32_t root, uint32_t n_ranks, const void* recv_device) {
+    if (!c || !recv_device) return fail(c, RT3_E_INVALID, "gather_unpack: NULL argument");
+    Resource* r = get_res(c, image, RT3_TAG_IMAGE);
+    if (!r || format_bytes(r->format) != 16) return fail(c, RT3_E_INVALID, "the gather needs a 16-byte-per-pixel image");
+    HIPC(c, hipSetDevice(c->device));
+    GatherLayout* gl;
+    if (int e = get_gather_layout(c, r->w, r->h, root, n_ranks, &gl)) return e;
+    const uint64_t total = gl->off[n_ranks];
+    if (total) launch_unpack_tiles(c->stream, gl->dev, (uint32_t)total, r->w, recv_device, r->ptr);  // ONE launch for all ranks
+    HIPC(c, hipGetLastError());
+    return RT3_OK;
+}
+int rt3_gather_tiles(rt3_ctx* c, uint32_t image, uint32_t root) {
+    if (!c) return RT3_E_INVALID;
+    if (!c->comm) return fail(c, RT3_E_STATE, "gather_tiles: call rt3_comm_init first");
+    Resource* r = get_res(c, image, RT3_TAG_IMAGE);
+    if (!r || format_bytes(r->format) != 16) return fail(c, RT3_E_INVALID, "the gather needs a 16-byte-per-pixel image");
+    const uint32_t n = c->comm_size, me = c->comm_rank;
+    if (root >= n) return fail(c, RT3_E_INVALID, "gather_tiles: root must be < n_ranks");
+    if (c->n_ranks != n || c->rank != me)
+        return fail(c, RT3_E_STATE, "gather_tiles: the tile partition (rt3_set_tile_partition) and the communicator disagree on rank / n_ranks");
+    if (n == 1) return RT3_OK;  // the frame is already whole
+    HIPC(c, hipSetDevice(c->device));
+    if (me != root) {
+        PixelList* pl;
+        if (int e = get_pixlist(c, r->w, r->h, me, n, &pl)) return e;
+        if (pl->count == 0) return RT3_OK;  // (the root skips empty ranks too)
+        if (int e = ensure_gather_buf(c, (size_t)pl->count * 16)) return e;
+        {
+            ScopedTimer t(c, CAT_OTHER);
+            launch_pack_tiles(c->stream, pl->dev, pl->count, r->w, r->ptr, c->gather_buf);
+        }
+        HIPC(c, hipGetLastError());
+        ScopedTimer t(c, CAT_GATHER);
+        NCCLC(c, ncclSend(c->gather_buf, (size_t)pl->count * 4, ncclFloat, (int)root, c->comm, c->stream));
+        return RT3_OK;
+    }
+    GatherLayout* gl;
+    if (int e = get_gather_layout(c, r->w, r->h, root, n, &gl)) return e;
+    const uint64_t total = gl->off[n];
+    if (total == 0) return RT3_OK;
+    if (int e = ensure_gather_buf(c, (size_t)total * 16)) return e;
+    {
+        // exact per-rank counts at exact offsets, every peer's recv in ONE group = one gather; xGMI is point to point, so the
+        // root's inbound links run concurrently and nothing is forwarded (a ring would move (n-1) x the bytes)
+        ScopedTimer t(c, CAT_GATHER);
+        NCCLC(c, ncclGroupStart());
+        for (uint32_t p = 0; p < n; p++) {
+            const uint64_t cnt = gl->off[p + 1] - gl->off[p];
+            if (p == root || cnt == 0) continue;
+            ncclResult_t e = ncclRecv((char*)c->gather_buf + gl->off[p] * 16, (size_t)cnt * 4, ncclFloat, (int)p, c->comm, c->stream);
+            if (e != ncclSuccess) {
+                (void)ncclGroupEnd();
+                return fail(c, RT3_E_COMM, std::string("ncclRecv: ") + ncclGetErrorString(e));
+            }
+        }
+        NCCLC(c, ncclGroupEnd());
+    }
+    ScopedTimer t(c, CAT_OTHER);
+    launch_unpack_tiles(c->stream, gl->dev, (uint32_t)total, r->w, c->gather_buf, r->ptr);  // stream-ordered behind the receives
     HIPC(c, hipGetLastError());
     return RT3_OK;
 }

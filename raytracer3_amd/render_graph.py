@@ -246,6 +246,32 @@ class Context:
         self.check(self.lib.rt3_tile_pixel_count(self.h, rank, n_ranks, C.byref(out)))
         return out.value
 
+    # ---- frame-end gather (include/rt3.h: rt3_comm_* / rt3_gather_*)
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(L.COMM_ID_BYTES)
+        rc = self.lib.rt3_comm_unique_id(buf)
+        if rc != 0:
+            raise L.Rt3Error(rc, self.lib.rt3_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, uid: bytes, rank: int, n_ranks: int):
+        assert len(uid) == L.COMM_ID_BYTES
+        self.check(self.lib.rt3_comm_init(self.h, C.c_char_p(uid), rank, n_ranks))
+
+    def comm_destroy(self):
+        self.check(self.lib.rt3_comm_destroy(self.h))
+
+    def gather_tiles(self, image, root=0):
+        self.check(self.lib.rt3_gather_tiles(self.h, image, root))
+
+    def gather_layout(self, image, root, n_ranks):
+        off = (C.c_uint64 * (n_ranks + 1))()
+        self.check(self.lib.rt3_gather_layout(self.h, image, root, n_ranks, off))
+        return [int(x) for x in off]
+
+    def gather_unpack(self, image, root, n_ranks, recv_device_ptr):
+        self.check(self.lib.rt3_gather_unpack(self.h, image, root, n_ranks, C.c_void_p(recv_device_ptr)))
+
 
 class NodeBuilder:
     """build.rs:32-209"""

@@ -55,7 +55,8 @@ class PathTracer:
         self.ctx.set_tile_partition(self.window[0], self.window[1], rank, n_ranks)
         self.rg = RenderGraph(self.ctx, self.window)
         self._accel = None
-        self.host_staged_gather = False  # rehearsal only: gather through host tensors (gloo) instead of device tensors (nccl/RCCL)
+        self.comm_ready = False  # True once init_comm() has joined librt3's RCCL communicator
+        self._stage = None       # rehearsal path only: staging buffer of the host-moved gather
 
     def close(self):
         self.ctx.close()
@@ -158,51 +159,70 @@ class PathTracer:
         """Progressive accumulation: PrevLight <- Light (refrence_mode.slang:11,61-65)."""
         self.rg.upload(self.handles["prev"], self.light())
 
-    # ---- multi-GPU: one gather of the per-rank tile buffers at frame end (torch.distributed, backend nccl == RCCL)
+    # ---- multi-GPU: ONE gather of the per-rank tile buffers at frame end (include/rt3.h: rt3_gather_tiles, RCCL inside librt3)
     def tile_pixel_count(self, rank):
         return self.ctx.tile_pixel_count(rank, self.n_ranks)
 
+    def init_comm(self, uid: bytes):
+        """Collective over all ranks: join librt3's own RCCL communicator.  `uid` is rank 0's `ctx.comm_unique_id()`, carried to the
+        other ranks by the host (bench.py: through the torch.distributed key-value store)."""
+        self.ctx.comm_init(uid, self.rank, self.n_ranks)
+        self.comm_ready = True
+
     def gather_light(self, dist=None, torch=None, dst=0, download=True):
-        """Pack this rank's tiles of `Light`, gather them on `dst` with ONE collective and untile there.
-        Returns the full (H, W, 4) image on `dst` (None elsewhere); with download=False the assembled frame stays in
-        `dst`'s HBM (the `Light` image) and True is returned instead.  With n_ranks == 1 no collective is issued."""
-        if self.n_ranks == 1:
-            return self.light() if download else True
-        counts = [self.tile_pixel_count(r) for r in range(self.n_ranks)]
-        dev = torch.device("cuda", torch.cuda.current_device())
-        lib, h, img = self.ctx.lib, self.ctx.h, self.handles["light"]
-
-        def pack(buf):
-            torch.cuda.synchronize()  # torch zero-fills `buf` on ITS stream; librt3 writes it on another one
-            self.ctx.check(lib.rt3_image_pack_tiles(h, img, self.rank, self.n_ranks, C.c_void_p(buf.data_ptr())))
-            self.ctx.wait()  # librt3 runs on its own stream: the tile buffer must be complete before RCCL reads it
-
-        def unpack(r, buf):
-            torch.cuda.synchronize()
-            self.ctx.check(lib.rt3_image_unpack_tiles(h, img, r, self.n_ranks, C.c_void_p(buf.data_ptr())))
-
-        # The untile kernels run asynchronously on librt3's stream, which torch's caching allocator knows nothing about: every
-        # buffer they read must stay alive until that stream has drained (`finish`), or the allocator hands the block to the
-        # next tensor while a kernel still reads it.
-        if self.host_staged_gather:
-            staged = []
-
-            def pack_host(buf):
-                g = torch.zeros_like(buf, device=dev)
-                pack(g)
-                buf.copy_(g.cpu())
-
-            def unpack_host(r, buf):
-                staged.append(buf.to(dev))
-                unpack(r, staged[-1])
-
-            done = gather_tiles(dist, torch, torch.device("cpu"), self.rank, self.n_ranks, counts, pack_host, unpack_host, dst, finish=self.ctx.wait)
-            staged.clear()
-        else:
-            done = gather_tiles(dist, torch, dev, self.rank, self.n_ranks, counts, pack, unpack, dst, finish=self.ctx.wait)
-        if not done:
-            return None
+        """Assemble the frame on rank `dst` from every rank's tiles of `Light` with the frame's one collective.
+        With a communicator (`init_comm`): `rt3_gather_tiles`, enqueued on librt3's stream, no host synchronisation.
+        Without one (REHEARSAL on a one-GPU box, `RT3_DIST_BACKEND=gloo`): the same layout and the same single untile launch
+        (`rt3_gather_layout` / `rt3_gather_unpack`), the bytes moved through host tensors by `exchange_tiles_host`.
+        Returns the full (H, W, 4) image on `dst` (None elsewhere); with download=False the assembled frame stays in `dst`'s HBM
+        (the `Light` image) and True is returned on `dst` instead.  With n_ranks == 1 no collective is issued."""
+        img = self.handles["light"]
+        if self.n_ranks > 1:
+            if self.comm_ready:
+                self.ctx.gather_tiles(img, dst)
+            else:
+                off = self.ctx.gather_layout(img, dst, self.n_ranks)
+                mine = None
+                if self.rank != dst:
+                    n = self.tile_pixel_count(self.rank)
+                    if self._stage is None:
+                        self._stage = self.rg.buffer(max(n, 1) * 16, "gather_stage")
+                    ptr, _ = self.rg.device_ptr(self._stage)
+                    self.ctx.check(self.ctx.lib.rt3_image_pack_tiles(self.ctx.h, img, self.rank, self.n_ranks, C.c_void_p(ptr)))
+                    mine = self.rg.download(self._stage, (max(n, 1), 4), np.float32)[:n]
+                recv = exchange_tiles_host(dist, torch, self.rank, self.n_ranks, off, mine, dst)
+                if self.rank == dst and off[-1]:
+                    if self._stage is None:
+                        self._stage = self.rg.buffer(off[-1] * 16, "gather_stage")
+                    self.rg.upload(self._stage, recv)
+                    self.ctx.gather_unpack(img, dst, self.n_ranks, self.rg.device_ptr(self._stage)[0])
+            if self.rank != dst:
+                return None
         return self.light() if download else True
+
+
+def gather_offsets(counts, root):
+    """Pixel offsets of the frame-end gather's receive buffer (what `rt3_gather_layout` returns): ranks in ascending order, exact
+    counts, nothing from `root` itself (its tiles are already in its image).  n_ranks + 1 entries."""
+    off = [0]
+    for r, c in enumerate(counts):
+        off.append(off[-1] + (0 if r == root else int(c)))
+    return off
+
+
+def exchange_tiles_host(dist, torch, rank, n_ranks, offsets, mine, dst=0):
+    """Host-memory stand-in for the RCCL exchange inside `rt3_gather_tiles` (gloo: CPU tests, one-GPU rehearsal): every rank
+    but `dst` sends its packed tiles (n x 4 float32) point to point; `dst` receives rank r's at offsets[r]..offsets[r+1] of ONE
+    contiguous buffer, all receives posted together.  Returns that buffer on `dst`, None elsewhere."""
+    if rank != dst:
+        if mine is not None and len(mine):
+            dist.send(torch.from_numpy(np.ascontiguousarray(mine, np.float32)), dst)
+        return None
+    recv = torch.empty((offsets[-1], 4), dtype=torch.float32)
+    reqs = [dist.irecv(recv[offsets[r]:offsets[r + 1]], src=r) for r in range(n_ranks) if r != dst and offsets[r + 1] > offsets[r]]
+    for q in reqs:
+        q.wait()
+    return recv.numpy()
 
 
 def zcurve(x, y):
@@ -218,27 +238,6 @@ def zcurve(x, y):
 def sh_buffer_bytes(probes_x, probes_y):
     """Bytes of the float3x3 buffer spherical_harmonic_conversion writes at zcurve(3 * gx + c, gy) (48 B per element)."""
     return 48 * (zcurve(probes_x * 3 - 1, probes_y - 1) + 1)
-
-
-def gather_tiles(dist, torch, device, rank, n_ranks, counts, pack, unpack, dst=0, finish=None):
-    """The one collective of a frame (north_star): every rank contributes its contiguous tile buffer
-    (max(counts) x RGBA32F, zero padded) to ONE `dist.gather` on `dst`; `dst` hands each received buffer to `unpack`.
-    `pack(buf)` fills this rank's buffer, `unpack(r, buf)` scatters rank r's pixels into the full image.
-    `finish()` (optional) is called on `dst` after the last `unpack`, while the received buffers are still alive.
-    Backend-agnostic (nccl == RCCL on the GPUs, gloo in the CPU tests).  Returns True on `dst`."""
-    cap = max(counts)
-    mine = torch.zeros((cap, 4), dtype=torch.float32, device=device)
-    pack(mine)
-    if rank == dst:
-        parts = [torch.empty_like(mine) for _ in range(n_ranks)]
-        dist.gather(mine, parts, dst=dst)
-        for r, p in enumerate(parts):
-            unpack(r, p)
-        if finish is not None:
-            finish()
-        return True
-    dist.gather(mine, None, dst=dst)
-    return False
 
 
 def default_camera(window, position, direction, fov_deg):

@@ -1,5 +1,7 @@
-"""N > 1 path on CPU: two gloo ranks, each producing its interleaved 64x64 tiles (the oracle stands in for the GPU),
-ONE gather to rank 0 through the product's `gather_tiles`, untile, compare with the single-rank image."""
+"""N > 1 path on CPU: gloo ranks, each producing its interleaved 64x64 tiles (the oracle stands in for the GPU), ONE gather to
+the root through the product's host-memory exchange (`exchange_tiles_host`: the layout of `rt3_gather_tiles` -- exact per-rank
+counts at `gather_offsets`, nothing from the root itself), ONE untile over the whole receive buffer, compare with the
+single-rank image."""
 import os
 import socket
 import sys
@@ -24,12 +26,12 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_path, W, H):
+def _worker(rank, world, port, out_path, W, H, dst):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import orc
     from raytracer3_amd import assets, scenes
-    from raytracer3_amd.renderer import gather_tiles
+    from raytracer3_amd.renderer import exchange_tiles_host, gather_offsets
 
     mesh, sky, bn = scenes.atrium(0.15), scenes.sky(128, 64), assets.load_bluenoise()
     osc = orc.Scene(mesh, sky, bn)
@@ -38,33 +40,41 @@ def _worker(rank, world, port, out_path, W, H):
     g.pad[0] = orc.F_NEE_SKY | orc.F_BLUENOISE | orc.F_FACEFORWARD
     gb, depth = osc.gbuffer(g, threads=2)
     full, _ = osc.reference_mode(g, gb, depth, threads=2)  # every rank can compute the full image; it only SHIPS its tiles
-    mine_xy = orc.tile_pixels(W, H, rank, world)
-    counts = [len(orc.tile_pixels(W, H, r, world)) for r in range(world)]
+    lists = [orc.tile_pixels(W, H, r, world) for r in range(world)]
+    off = gather_offsets([len(x) for x in lists], dst)
+    assert off[-1] == W * H - len(lists[dst]) and off[dst + 1] == off[dst]
+    mine_xy = lists[rank]
     image = np.zeros((H, W, 4), np.float32)
-
-    def pack(buf):
-        buf[: len(mine_xy)] = torch.from_numpy(full[mine_xy[:, 1], mine_xy[:, 0]])
-
-    def unpack(r, buf):
-        xy = orc.tile_pixels(W, H, r, world)
-        image[xy[:, 1], xy[:, 0]] = buf[: len(xy)].numpy()
-
-    done = gather_tiles(dist, torch, torch.device("cpu"), rank, world, counts, pack, unpack, dst=0)
-    assert done == (rank == 0)
-    if rank == 0:
+    image[mine_xy[:, 1], mine_xy[:, 0]] = full[mine_xy[:, 1], mine_xy[:, 0]]  # a rank renders its own tiles into its own image
+    recv = exchange_tiles_host(dist, torch, rank, world, off, full[mine_xy[:, 1], mine_xy[:, 0]] if rank != dst else None, dst)
+    assert (recv is not None) == (rank == dst)
+    if rank == dst:
+        xy = np.concatenate([lists[r] for r in range(world) if r != dst])  # the ONE untile over all received ranks
+        assert len(xy) == len(recv)
+        image[xy[:, 1], xy[:, 0]] = recv
         np.save(out_path, np.stack([image, full]))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gather_reassembles_the_frame(tmp_path):
+@pytest.mark.parametrize("world,dst", [(2, 0), (3, 1)])
+def test_gather_reassembles_the_frame(tmp_path, world, dst):
     W, H = 200, 150  # 4 x 3 tiles with ragged right / bottom edges
     out = str(tmp_path / "img.npy")
-    mp.spawn(_worker, args=(2, _free_port(), out, W, H), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, W, H, dst), nprocs=world, join=True)
     image, full = np.load(out)
     assert np.array_equal(image.view(np.uint32), full.view(np.uint32))
     assert image[..., :3].mean() > 0
+
+
+def test_gather_offsets_skip_the_root():
+    from raytracer3_amd.renderer import gather_offsets
+
+    assert gather_offsets([5, 7, 9], 0) == [0, 0, 7, 16]
+    assert gather_offsets([5, 7, 9], 1) == [0, 5, 5, 14]
+    assert gather_offsets([5, 0, 9], 2) == [0, 5, 5, 5]
+    assert gather_offsets([4], 0) == [0, 0]
 
 
 def test_tile_partition_properties():

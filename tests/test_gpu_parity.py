@@ -430,6 +430,17 @@ def test_error_behaviour(small):
     gi = mesh.geometries.copy()
     gi["index_offset"][-1] = 2**31
     assert lib.rt3_scene_set_geometry(ctx.h, gi.ctypes.data, pc.ctypes.data, len(gi)) == L.E_INVALID
+    # ... also when the world buffers are replaced by smaller ones AFTER the geometry was accepted: rt3_accel_build re-checks
+    ctx.upload_mesh(mesh)
+    assert lib.rt3_accel_build(ctx.h, C.byref(out)) == 0
+    fewer = np.ascontiguousarray(mesh.vertices[: len(mesh.vertices) // 2], np.float32)
+    assert lib.rt3_scene_set_vertices(ctx.h, fewer.ctypes.data, len(fewer)) == 0
+    assert lib.rt3_accel_build(ctx.h, C.byref(out)) == L.E_INVALID and b"vertex range" in lib.rt3_last_error(ctx.h)
+    assert lib.rt3_pass_launch(ctx.h, b"gbuffer", b"main", 64, 64, 1, C.byref(g), 304, bb, 2) == L.E_STATE  # no stale BVH is used
+    ctx.upload_mesh(mesh)
+    short_idx = np.ascontiguousarray(mesh.indices[: len(mesh.indices) // 2], np.uint32)
+    assert lib.rt3_scene_set_indices(ctx.h, short_idx.ctypes.data, len(short_idx)) == 0
+    assert lib.rt3_accel_build(ctx.h, C.byref(out)) == L.E_INVALID and b"index range" in lib.rt3_last_error(ctx.h)
     ctx.close()
 
 
@@ -503,9 +514,9 @@ def test_full_size_frame_properties():
     would need minutes: (1) determinism -- out-of-order ray completion, atomics-based queue compaction and the dynamic ray
     pool must not leak into the image; (2) the frame does not depend on the rank count (1 vs 4 ranks, tiles merged);
     (3) linearity of the reference estimator: doubling every emission doubles the radiance exactly (power-of-two scaling
-    is exact in fp32); (4) sample batching (16 + 16 vs 4 x 8) leaves the bits alone; (5) closed-form bounds: finite,
+    is exact in fp32); (4) sample batching (one batch of 64 vs 4 x 16) leaves the bits alone; (5) closed-form bounds: finite,
     non-negative, background pixels untouched; (6) a 64 x 64 window of the frame against the oracle, bit for bit."""
-    W, H, spp, B = 1920, 1080, 32, 4
+    W, H, spp, B = 1920, 1080, 64, 4  # BASELINE configs[2] at its own size
     mesh, sky, bn = scenes.atrium(1.0), scenes.sky(2048, 1024), assets.load_bluenoise()
     cam = Camera(scenes.ATRIUM_CAMERA["position"], scenes.ATRIUM_CAMERA["direction"], math.radians(scenes.ATRIUM_CAMERA["fov_deg"]), W / H)
 
@@ -531,7 +542,7 @@ def test_full_size_frame_properties():
         xy = orc.tile_pixels(W, H, r, 4)
         merged[xy[:, 1], xy[:, 0]] = part[xy[:, 1], xy[:, 0]]
     assert np.array_equal(merged.view(np.uint32), a.view(np.uint32))
-    assert np.array_equal(render(SPEC, batch=8)[0].view(np.uint32), a.view(np.uint32))  # (4)
+    assert np.array_equal(render(SPEC, batch=16)[0].view(np.uint32), a.view(np.uint32))  # (4)
     bg = depth == L.BACKGROUND_DEPTH
     assert np.isfinite(a).all() and (a[..., :3] >= 0).all() and (a[bg] == 0).all() and 0.02 < bg.mean() < 0.9  # (5)
     e1 = render(0)[0]  # (3) reference estimator: emissive only
@@ -576,9 +587,10 @@ def test_fused_and_separate_traversal_launches_agree(small):
 
 
 def test_multi_rank_gather_rehearsal(tmp_path):
-    """bench.py --gpus 3 as the driver launches it (torch.distributed.run, one process per rank), in the rehearsal mode for a
-    1-GPU box (RT3_DIST_BACKEND=gloo: the ranks share GPU 0 and the one gather goes through host tensors): the frame
-    assembled on rank 0 from three ranks' tiles must be bit-identical to a single-rank render of it."""
+    """`python bench.py --gpus 3` exactly as the driver invokes it (no launcher on the command line): bench.py starts its three
+    ranks itself.  Rehearsal mode for a 1-GPU box (RT3_DIST_BACKEND=gloo: the ranks share GPU 0 and the gather's bytes move
+    through host tensors, laid out and untiled exactly like rt3_gather_tiles): the frame assembled on rank 0 from three ranks'
+    tiles must be bit-identical to a single-rank render of it."""
     import json
     import os
     import subprocess
@@ -586,14 +598,102 @@ def test_multi_rank_gather_rehearsal(tmp_path):
     from pathlib import Path
 
     root = Path(__file__).resolve().parent.parent
-    env = dict(os.environ, RT3_DIST_BACKEND="gloo", RT3_CHECK_GATHER="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1", "--master-port", "29533",
-           str(root / "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "1", "--no-cpu", "--width", "328", "--height", "200", "--spp", "4", "--detail", "0.3"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RT3_DIST_BACKEND="gloo", RT3_CHECK_GATHER="1")
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "3", "--steps", "1", "--warmup", "1", "--no-cpu", "--width", "328", "--height", "200", "--spp", "4", "--detail", "0.3"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=500)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 3 and d["gather_bit_identical_to_single_rank"] is True and d["value"] > 0
+    assert "REHEARSAL" in d["config"]["gather"]
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    """The same command on the real backend (RCCL cannot put two ranks on one GPU): with fewer than N visible devices it must exit
+    non-zero with a message, never report a 1-GPU number as the N-GPU point."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    import torch
+
+    n = torch.cuda.device_count() + 1
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RT3_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--no-cpu"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert "visible devices" in r.stderr and not any(ln.startswith("{") for ln in r.stdout.splitlines())
+
+
+def test_gather_layout_and_single_untile(small):
+    """The root's half of rt3_gather_tiles on one GPU (RCCL cannot put several ranks on one device, so the exchange itself stays
+    unmeasured here): every rank of a 3-rank partition renders its tiles in its own context, the non-root ranks pack them at the
+    EXACT offsets rt3_gather_layout reports into one receive buffer, and ONE rt3_gather_unpack launch on the root reassembles
+    the frame -- bit-identical to the single-rank render.  Root 1 of 3 (not rank 0) and a ragged window."""
+    from raytracer3_amd.renderer import gather_offsets
+
+    mesh, sky, bn, osc = small
+    W, H, n, root = 200, 150, 3, 1
+    cam = Camera(scenes.ATRIUM_CAMERA["position"], scenes.ATRIUM_CAMERA["direction"], math.radians(65.0), W / H)
+    solo = PathTracer((W, H))
+    solo.set_scene(mesh, sky, bn)
+    g = solo.make_gconst(cam, 2, 3, frame=2, flags=FULL)
+    solo.render(g)
+    ref = solo.light()
+    solo.close()
+    pts = [PathTracer((W, H), rank=r, n_ranks=n) for r in range(n)]
+    for pt in pts:
+        pt.set_scene(mesh, sky, bn)
+        pt.render(g)
+    rootpt = pts[root]
+    img = rootpt.handles["light"]
+    off = rootpt.ctx.gather_layout(img, root, n)
+    counts = [rootpt.ctx.tile_pixel_count(r, n) for r in range(n)]
+    assert off == gather_offsets(counts, root) and off[-1] == W * H - counts[root]
+    recv = rootpt.rg.buffer(off[-1] * 16, "recv")
+    ptr, nbytes = rootpt.rg.device_ptr(recv)
+    assert nbytes == off[-1] * 16
+    for r, pt in enumerate(pts):
+        if r == root:
+            continue
+        pt.ctx.check(pt.ctx.lib.rt3_image_pack_tiles(pt.ctx.h, pt.handles["light"], r, n, C.c_void_p(ptr + off[r] * 16)))
+        pt.ctx.wait()
+    before = rootpt.light()
+    assert not np.array_equal(before.view(np.uint32), ref.view(np.uint32))  # the root alone holds only its own tiles
+    rootpt.ctx.gather_unpack(img, root, n, ptr)
+    assert np.array_equal(rootpt.light().view(np.uint32), ref.view(np.uint32))
+    for pt in pts:
+        pt.close()
+
+
+def test_rccl_communicator_single_rank(small):
+    """The RCCL entry points on the one GPU a test box has: unique id, ncclCommInitRank with one rank, the (trivial) gather,
+    destroy -- and the state errors around them."""
+    mesh, sky, bn, osc = small
+    W, H = 128, 64
+    pt = PathTracer((W, H))
+    pt.set_scene(mesh, sky, bn)
+    cam = Camera(scenes.ATRIUM_CAMERA["position"], scenes.ATRIUM_CAMERA["direction"], math.radians(65.0), W / H)
+    pt.render(pt.make_gconst(cam, 1, 2, flags=FULL))
+    ref = pt.light()
+    lib, h, img = pt.ctx.lib, pt.ctx.h, pt.handles["light"]
+    assert lib.rt3_gather_tiles(h, img, 0) == L.E_STATE and b"rt3_comm_init" in lib.rt3_last_error(h)
+    uid = pt.ctx.comm_unique_id()
+    assert len(uid) == L.COMM_ID_BYTES and any(uid)
+    assert lib.rt3_comm_init(h, uid, 1, 1) == L.E_INVALID  # rank must be < n_ranks
+    pt.init_comm(uid)
+    assert lib.rt3_comm_init(h, uid, 0, 1) == L.E_STATE   # already has a communicator
+    assert lib.rt3_gather_tiles(h, img, 1) == L.E_INVALID  # root out of range
+    pt.ctx.gather_tiles(img, 0)  # one rank: the frame is already whole
+    assert np.array_equal(pt.light().view(np.uint32), ref.view(np.uint32))
+    pt.ctx.set_tile_partition(W, H, 1, 2)  # the partition and the communicator must agree
+    assert lib.rt3_gather_tiles(h, img, 0) == L.E_STATE and b"disagree" in lib.rt3_last_error(h)
+    pt.ctx.comm_destroy()
+    pt.ctx.comm_destroy()  # idempotent
+    assert lib.rt3_gather_tiles(h, img, 0) == L.E_STATE
+    pt.close()
 
 
 def test_lbvh_large_scene_bit_identical():

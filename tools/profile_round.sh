@@ -11,5 +11,6 @@ timeout -k 10 500 python3 bench.py > "$out/bench.log" 2>&1; tail -1 "$out/bench.
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 2 --warmup 1 --no-cpu > "$out/bench_trace.log" 2>&1
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 1 --warmup 0 --no-cpu > "$out/bench_pmc_fetch.log" 2>&1
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 1 --warmup 0 --no-cpu > "$out/bench_pmc_write.log" 2>&1
-timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU --output-format csv -d "$out/pmc_sq" -- python3 bench.py --steps 1 --warmup 0 --no-cpu > "$out/bench_pmc_sq.log" 2>&1
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU GRBM_GUI_ACTIVE --output-format csv -d "$out/pmc_sq" -- python3 bench.py --steps 1 --warmup 0 --no-cpu > "$out/bench_pmc_sq.log" 2>&1
+python3 tools/summarize_profile.py "$out" "$out/summary" && cp "$out"/trace/*/*_kernel_stats.csv "$out/kernel_stats.csv" 2>/dev/null || true
 echo "profile_round $tag done"

@@ -16,11 +16,13 @@ def short(name):
 def main(src, dst):
     lines = ["# rocprofv3 summary (" + src + ")", ""]
     traffic = {}
+    avg_ms = {}
     st = glob.glob(f"{src}/trace/**/*_kernel_stats.csv", recursive=True)
     if st:
         lines += ["## --kernel-trace --stats (all dispatches of the profiled command)", "", "| kernel | calls | total ms | avg ms | % |", "|---|---|---|---|---|"]
         for r in csv.DictReader(open(st[0])):
             lines.append(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['TotalDurationNs'])/1e6:.3f} | {float(r['AverageNs'])/1e6:.4f} | {float(r['Percentage']):.2f} |")
+            avg_ms[short(r["Name"])] = float(r["AverageNs"]) / 1e6
         lines.append("")
     for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
         fs = glob.glob(f"{src}/{tag}/**/*_counter_collection.csv", recursive=True)
@@ -40,28 +42,47 @@ def main(src, dst):
             traffic.setdefault(k, {})[ctr] = v * 1024.0 / n  # bytes per dispatch, as reported
         lines.append("")
     sq = glob.glob(f"{src}/pmc_sq/**/*_counter_collection.csv", recursive=True)
+    sqinfo = {}
     if sq:
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        span = collections.defaultdict(dict)  # kernel -> dispatch id -> (start, end) ns of the profiled dispatch itself
         for r in csv.DictReader(open(sq[0])):
-            agg[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
-        lines += ["## --pmc SQ_* (separate pass, one frame; WAIT_ANY = parked on s_waitcnt / barrier, WAIT_INST_ANY = issue stall)", "",
-                  "| kernel | WAVE_CYCLES | ACTIVE_INST_ANY | WAIT_INST_ANY | WAIT_ANY | INSTS_VALU | INSTS_VMEM_RD |", "|---|---|---|---|---|---|---|"]
+            k = short(r["Kernel_Name"])
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            if r.get("Start_Timestamp") and r.get("End_Timestamp"):
+                span[k][r["Dispatch_Id"]] = (float(r["Start_Timestamp"]), float(r["End_Timestamp"]))
+        lines += ["## --pmc SQ_* + GRBM_GUI_ACTIVE (separate pass, one frame; WAIT_ANY = parked on s_waitcnt / barrier, WAIT_INST_ANY = issue stall)", "",
+                  "Effective clock = GRBM_GUI_ACTIVE / 8 XCDs / dispatch time (MI355X_MICROARCH.md, DVFS); VALU issue = SQ_INSTS_VALU (wave instructions) per",
+                  "clock per SIMD (1024 SIMDs); a wave64 VALU instruction holds its SIMD-32 for two cycles, so the ceiling is 0.5.", "",
+                  "| kernel | WAVE_CYCLES | ACTIVE_INST_ANY | WAIT_INST_ANY | WAIT_ANY | INSTS_VALU | INSTS_VMEM_RD | time ms | clock GHz | VALU / clk / SIMD | of 0.5 |", "|---|---|---|---|---|---|---|---|---|---|---|"]
         for k, v in agg.items():
             wc = v.get("SQ_WAVE_CYCLES", 0.0)
             if wc > 1e9:
-                lines.append(f"| `{k}` | {wc:.3g} | {v['SQ_ACTIVE_INST_ANY'] / wc:.1%} | {v['SQ_WAIT_INST_ANY'] / wc:.1%} | {v['SQ_WAIT_ANY'] / wc:.1%} | {v['SQ_INSTS_VALU']:.3g} | {v['SQ_INSTS_VMEM_RD']:.3g} |")
+                t_ns = sum(e - s for s, e in span[k].values())
+                clk = v.get("GRBM_GUI_ACTIVE", 0.0) / 8.0 / t_ns if t_ns > 0 and v.get("GRBM_GUI_ACTIVE") else 0.0  # GHz
+                use_clk = clk if 1.0 < clk < 2.6 else 2.4
+                vpc = v["SQ_INSTS_VALU"] / (t_ns * use_clk * 1024.0) if t_ns > 0 else 0.0
+                sqinfo[k] = {"valu_per_clk_per_simd": round(vpc, 4), "clock_ghz": round(use_clk, 3), "wait_any": round(v["SQ_WAIT_ANY"] / wc, 4),
+                             "wait_inst_any": round(v["SQ_WAIT_INST_ANY"] / wc, 4), "active_inst_any": round(v["SQ_ACTIVE_INST_ANY"] / wc, 4)}
+                lines.append(f"| `{k}` | {wc:.3g} | {v['SQ_ACTIVE_INST_ANY'] / wc:.1%} | {v['SQ_WAIT_INST_ANY'] / wc:.1%} | {v['SQ_WAIT_ANY'] / wc:.1%} | {v['SQ_INSTS_VALU']:.3g} | "
+                             f"{v['SQ_INSTS_VMEM_RD']:.3g} | {t_ns / 1e6:.2f} | {use_clk:.2f} | {vpc:.3f} | {vpc / 0.5:.1%} |")
         lines.append("")
     for log in sorted(glob.glob(f"{src}/bench*.log")):
         for ln in open(log):
             if ln.startswith("{"):
                 lines += [f"## bench line under `{log.split('/')[-1]}`", "", "```json", ln.strip(), "```", ""]
     if traffic:
-        # MI355X_MICROARCH.md §HBM: the counters report KiB; on gfx950 FETCH_SIZE tallies 16 B/lane reads at half their bytes
-        # (every load in these kernels is a 16-byte lane request) -> doubled; WRITE_SIZE is exact for 16 B/lane stores.
-        out = {k: {"fetch_bytes_raw": v.get("FETCH_SIZE"), "write_bytes": v.get("WRITE_SIZE"),
-                   "hbm_bytes_per_launch": 2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)} for k, v in traffic.items()}
-        json.dump({"source": src, "correction": "2*FETCH_SIZE + WRITE_SIZE (KiB->bytes; gfx950 16 B/lane read correction)", "kernels": out},
-                  open(dst + "_traffic.json", "w"), indent=1)
+        # profiles/r02_fetch_calibration.md: FETCH_SIZE tallies 64 B per 128-byte line request leaving L2, whatever the access shape
+        # (coalesced streams, 16 / 64 / 128-byte random records), Infinity-Cache hits included; WRITE_SIZE is exact.  So
+        # 2 x FETCH_SIZE + WRITE_SIZE = fabric-side (L2-miss) bytes, an upper bound of HBM traffic, for gathers as for streams.
+        out = {}
+        for k, v in traffic.items():
+            e = {"fetch_bytes_raw": v.get("FETCH_SIZE", 0.0), "write_bytes": v.get("WRITE_SIZE", 0.0),
+                 "hbm_bytes_per_launch": 2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0), "avg_ms": avg_ms.get(k)}
+            e.update(sqinfo.get(k, {}))
+            out[k] = e
+        json.dump({"source": src, "correction": "2*FETCH_SIZE + WRITE_SIZE = fabric-side (L2-miss) bytes incl. Infinity-Cache hits; the factor 2 is calibrated for streams AND "
+                                                "16/64/128 B gathers in profiles/r02_fetch_calibration.md", "kernels": out}, open(dst + "_traffic.json", "w"), indent=1)
     open(dst + ".md", "w").write("\n".join(lines))
     print("wrote", dst + ".md")
 
