@@ -156,8 +156,20 @@ class PathTracer:
         return self.rg.download(self.handles["gbuffer"], (H, W, 4), np.uint32), self.rg.download(self.handles["depth"], (H, W), np.float32)
 
     def copy_light_to_prev(self):
-        """Progressive accumulation: PrevLight <- Light (refrence_mode.slang:11,61-65)."""
+        """Progressive accumulation: PrevLight <- Light (refrence_mode.slang:11,61-65), through the host (tests)."""
         self.rg.upload(self.handles["prev"], self.light())
+
+    def swap_light_prev(self):
+        """Progressive accumulation without a copy: the two images trade names, so the next frame's `PrevLight` is this frame's
+        `Light` (refrence_mode.slang:10-11,61-65; the reference's two images are distinct resources as well)."""
+        n = self.rg.named
+        n["Light"], n["PrevLight"] = n["PrevLight"], n["Light"]
+
+    def load_prev(self, image):
+        """Resume a progressive render: `image` (H, W, 4) float32 becomes the next frame's `PrevLight` (checkpoint row)."""
+        W, H = self.window
+        h = self.rg.image(ImageSize.FullScreen, L.FORMAT_R32G32B32A32_SFLOAT, "PrevLight")
+        self.rg.upload(h, np.ascontiguousarray(image, np.float32).reshape(H, W, 4))
 
     # ---- multi-GPU: ONE gather of the per-rank tile buffers at frame end (include/rt3.h: rt3_gather_tiles, RCCL inside librt3)
     def tile_pixel_count(self, rank):

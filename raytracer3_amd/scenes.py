@@ -4,6 +4,10 @@
 * `atrium(detail)`  Sponza stand-in: two-storey colonnade around an open-roofed court, floor tiles, draped curtains,
                     emissive ceiling panels.  detail=1.0 -> 262 144 +- 2 % triangles, AABB 29.8 x 12.4 x 18.3 m.
 * `cornell()`       closed Cornell box with an emissive ceiling panel (reference semantics need no sky).
+* `cornell_ref()`   the box of the ONE image the reference tree holds (resources/refrence.png, a Blender-Cycles render): the eight
+                    unit cubes and eight materials of the reference's processed asset `imported_assets/Default/box.glb`, placed
+                    (the asset lost its node transforms and its emission) so that a render from CORNELL_REF_CAMERA lines up with
+                    that image.  Informational: Cycles is not this estimator and the display transforms differ.
 * `sky(w, h)`       equirect RGB32F gradient sky + 0.5 degree sun disc (peak radiance 5e4).
 All surfaces carry normals facing the side they are meant to be seen from.
 """
@@ -19,6 +23,12 @@ ATRIUM_CAMERA = dict(position=(-10.0, 2.0, 0.0), direction=(1.0, 0.1, 0.0), fov_
 # slightly off-axis: an exactly symmetric view sends rays through the shared diagonals of the wall quads, where the fp32
 # Moeller-Trumbore test is not watertight (known limitations)
 CORNELL_CAMERA = dict(position=(0.0137, 1.0071, 3.4), direction=(0.0041, -0.0033, -1.0), fov_deg=40.0)
+
+
+# Fitted to /root/reference/resources/refrence.png (1920x1080): least squares over the eight interior corners of the box as they
+# appear in the image (box interior = the asset's unit cube [-1, 1]^3, open towards +z), no camera roll: 7 px RMS.
+CORNELL_REF_CAMERA = dict(position=(-0.18653, 0.33087, 7.38676), direction=(0.018591, -0.058248, -0.998129), fov_deg=22.8837)
+CORNELL_REF_EMISSION = 0.48  # GeometryInfo.emission of the light cube (x 12 in hit_info); chosen by tools/fit_cornell_ref.py
 
 
 def _grid(origin, du, dv, nu, nv, normal=None, disp=None):
@@ -238,6 +248,73 @@ def cornell() -> Mesh:
     mb.add("panel", *_grid([-0.35, 1.995, -0.35], [0.7, 0, 0], [0, 0, 0.7], 2, 2), light)
     _box(mb, "tall", [-0.65, 0.0, -0.65], [-0.05, 1.2, -0.05], white, n=2)
     _box(mb, "short", [0.1, 0.0, 0.0], [0.7, 0.6, 0.6], white, n=2)
+    return mb.build()
+
+
+def cornell_ref(asset_path=None, emission: float = CORNELL_REF_EMISSION) -> Mesh:
+    """The Cornell box of resources/refrence.png rebuilt from the reference's own processed asset.
+
+    `imported_assets/Default/box.glb` (bincode, older `Mesh` layout; tests/golden/processed_box.glb.bin is a byte-identical copy
+    so that this also works where /root/reference is absent) holds 8 unit cubes (24 vertices each: position, face normal, uv)
+    and 8 materials -- 0.8 grey x3, blue, red, green, 0.5 grey, 0.8 grey with roughness 0.5 -- but neither node transforms nor
+    emission.  Cube k takes material k; which cube is which wall is decided by its colour, the placements below
+    are read off the image: open front, black outside, a flat emissive box just under the ceiling (its side faces are what
+    lights the ceiling in the image: the render is direct light only -- the unlit front of the small box is pure black)."""
+    from pathlib import Path
+
+    from .assets import read_processed_mesh
+
+    path = Path(asset_path) if asset_path else Path(__file__).resolve().parent.parent / "tests" / "golden" / "processed_box.glb.bin"
+    pm = read_processed_mesh(path, "old")
+    if len(pm.materials) != 8 or len(pm.vertices) != 8 * 24:
+        raise ValueError("expected the reference's box asset: 8 cubes x 24 vertices, 8 materials")
+
+    def role(m):
+        r, g, b = m.color
+        if b > 0.5 and r < 0.1:
+            return "right"
+        if r > 0.5 and g < 0.1:
+            return "left"
+        if g > 0.5 and r < 0.1:
+            return "floor"
+        if abs(r - 0.5) < 0.01:
+            return "short"
+        return "light" if m.roughness_factor < 0.9 else "grey"
+
+    t = 0.05  # wall thickness (never seen: the outside is black)
+    place = {  # role -> (half size, centre, rotation about +y in degrees)
+        "floor": ((1 + 2 * t, t, 1.0), (0.0, -1 - t, 0.0), 0.0),
+        "ceiling": ((1 + 2 * t, t, 1.0), (0.0, 1 + t, 0.0), 0.0),
+        "back": ((1 + 2 * t, 1 + 2 * t, t), (0.0, 0.0, -1 - t), 0.0),
+        "left": ((t, 1.0, 1.0), (-1 - t, 0.0, 0.0), 0.0),
+        "right": ((t, 1.0, 1.0), (1 + t, 0.0, 0.0), 0.0),
+        "tall": ((0.247, 0.455, 0.25), (-0.535, -0.545, -0.37), -10.0),
+        "short": ((0.215, 0.19, 0.22), (0.28, -0.81, 0.27), 0.0),
+        "light": ((0.455, 0.02, 0.625), (-0.015, 0.975, -0.025), 0.0),
+    }
+    greys = iter(("back", "ceiling", "tall"))
+    mb = MeshBuilder()
+    for k, m in enumerate(pm.materials):
+        r = role(m)
+        name = next(greys) if r == "grey" else r
+        half, centre, rot = place[name]
+        v = pm.vertices[24 * k : 24 * k + 24].astype(np.float64)
+        c, sn = np.cos(np.radians(rot)), np.sin(np.radians(rot))
+        R = np.array([[c, 0.0, sn], [0.0, 1.0, 0.0], [-sn, 0.0, c]])
+        pos = (v[:, :3] * np.asarray(half)) @ R.T + np.asarray(centre)
+        nrm = v[:, 3:6] @ R.T  # axis-aligned face normals: unchanged by the axis-aligned scale
+        tris = []
+        for f in np.unique(np.round(v[:, 3:6]), axis=0):  # the four vertices of each face, fanned counter-clockwise about the outward normal
+            idx = np.nonzero((np.round(v[:, 3:6]) == f).all(1))[0]
+            assert len(idx) == 4
+            ctr = v[idx, :3].mean(0)
+            a = np.cross(f, [1.0, 0.0, 0.0]) if abs(f[0]) < 0.5 else np.cross(f, [0.0, 1.0, 0.0])
+            bq = np.cross(f, a)
+            ang = np.arctan2((v[idx, :3] - ctr) @ bq, (v[idx, :3] - ctr) @ a)
+            q = idx[np.argsort(ang)]
+            tris += [[q[0], q[1], q[2]], [q[0], q[2], q[3]]]
+        mat = Material(m.color, m.metalic_factor, m.roughness_factor, (emission,) * 3 if name == "light" else (0.0, 0.0, 0.0))
+        mb.add(name, pos, nrm, v[:, 6:8], np.asarray(tris), mat)
     return mb.build()
 
 

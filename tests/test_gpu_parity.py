@@ -280,6 +280,18 @@ def test_frame_parity_cornell_reference_semantics(cornell):
     ctx.close()
 
 
+def test_frame_parity_cornell_ref():
+    """The box rebuilt from the reference's processed asset (scenes.cornell_ref), direct light as in resources/refrence.png
+    (reference semantics, B = 2): radiance and the display image against the oracle."""
+    mesh = scenes.cornell_ref()
+    osc = orc.Scene(mesh)
+    g, light, gb, depth, col, _ = render_both(mesh, None, None, osc, 160, 90, scenes.CORNELL_REF_CAMERA, 8, 2, 0)
+    ogb, odepth = osc.gbuffer(as_orc(g))
+    olight, _ = osc.reference_mode(as_orc(g), ogb, odepth)
+    assert np.array_equal(depth, odepth) and np.array_equal(light.view(np.uint32), olight.view(np.uint32))
+    assert light[..., :3].max() > 1.0 and (depth < 1e5).mean() > 0.2
+
+
 def test_frame_parity_textured_cornell():
     """base-colour textures (hit_logic.slang:31-33): sRGB decode, bilinear, repeat addressing -- bit-exact vs the oracle"""
     mesh = scenes.textured_cornell()

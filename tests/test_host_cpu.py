@@ -216,3 +216,35 @@ def test_processed_asset_cache_decodes_the_reference_fixture(tmp_path):
     back = assets.read_processed_mesh(q)
     assert np.array_equal(back.meshlets, pm2.meshlets) and np.array_equal(back.vertices, pm2.vertices) and np.array_equal(back.indices, pm2.indices)
     assert back.uploaded is True and [m.color for m in back.materials] == [m.color for m in pm2.materials]
+
+
+def test_cornell_ref_is_built_from_the_reference_asset():
+    """scenes.cornell_ref(): the eight cubes / materials of the reference's processed box.glb (decoded, not hard-coded), placed to
+    match resources/refrence.png.  The camera fit is checked on the eight interior corners measured in that image (7 px RMS)."""
+    import math
+
+    from raytracer3_amd import assets, scenes
+
+    pm = assets.read_processed_mesh(ROOT / "tests" / "golden" / "processed_box.glb.bin", "old")
+    mesh = scenes.cornell_ref()
+    assert len(mesh.geometries) == 8 and mesh.n_triangles == 8 * 12 and len(mesh.vertices) == 8 * 24
+    for k, m in enumerate(pm.materials):  # cube k carries material k of the asset
+        assert np.allclose(mesh.geometries["base_color"][k][:3], m.color) and mesh.geometries["roughness"][k] == np.float32(m.roughness_factor)
+    lit = [n for n, e in zip(mesh.names, mesh.geometries["emission"]) if e[0] > 0]
+    assert lit == ["light"] and sorted(mesh.names) == sorted(["back", "ceiling", "right", "left", "floor", "short", "tall", "light"])
+    # project the interior corners of the [-1, 1]^3 box with the fitted camera and compare with their pixel positions in refrence.png
+    measured = {(-1, 1, -1): (644, 185), (-1, -1, -1): (657, 803), (-1, -1, 1): (580, 941), (-1, 1, 1): (560, 114),
+                (1, -1, 1): (1406, 929), (1, -1, -1): (1286, 800), (1, 1, -1): (1287, 162), (1, 1, 1): (1404, 92)}
+    g = orc.camera_gconst(width=1920, height=1080, **scenes.CORNELL_REF_CAMERA)
+    view, proj = np.array(g.view[:], np.float64).reshape(4, 4).T, np.array(g.proj[:], np.float64).reshape(4, 4).T
+    err = []
+    for p, (x, y) in measured.items():
+        c = proj @ view @ np.array([*p, 1.0])
+        err += [(c[0] / c[3] + 1) / 2 * 1920 - x, (1 - c[1] / c[3]) / 2 * 1080 - y]
+    assert math.sqrt(np.mean(np.square(err))) < 9.0
+    osc = orc.Scene(mesh)
+    g = orc.camera_gconst(width=96, height=54, **scenes.CORNELL_REF_CAMERA)
+    g.bounces, g.samples, g.blendfactor = 2, 8, 1.0
+    gb, depth = osc.gbuffer(g, threads=2)
+    light, _ = osc.reference_mode(g, gb, depth, threads=2)
+    assert 0.2 < (depth < 1e5).mean() < 0.5 and light[..., :3].max() > 1.0 and light[0, 0, :3].sum() == 0  # box in the middle, black outside

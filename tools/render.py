@@ -3,8 +3,10 @@
 (BASELINE.json configs[4]: accumulation over passes with blendfactor = 1/(pass+1), RMSE-vs-spp curve against the final image).
 
   python tools/render.py --scene atrium --size 960x540 --spp 64 --passes 16 --out gpurun_out/atrium.png --curve gpurun_out/curve.json
-  python tools/render.py --scene cornell --size 960x540 --spp 100 --compare resources/refrence_480x270.png   (informational only;
-                          a 480x270 copy of the reference tree's resources/refrence.png, a Blender-Cycles Cornell box)
+  python tools/render.py --scene cornell_ref --size 1920x1080 --spp 64 --passes 64 --bounces 2 --flags 0 \
+                         --compare resources/refrence_480x270.png --side-by-side profiles/r02_cornell_ref_side_by_side.png
+                          (informational only: a 480x270 copy of the reference tree's resources/refrence.png, a Blender-Cycles render of
+                          the box scenes.cornell_ref() rebuilds from the reference's processed asset; Cycles is not this estimator)
   python tools/render.py --glb resources/sponza_scene.glb --exr resources/skybox2.exr ...               (if the real assets are dropped in)
 """
 import argparse
@@ -22,7 +24,7 @@ sys.path.insert(0, str(ROOT))
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--scene", default="atrium", choices=["atrium", "cornell"])
+    ap.add_argument("--scene", default="atrium", choices=["atrium", "cornell", "cornell_ref"])
     ap.add_argument("--glb", default=None)
     ap.add_argument("--exr", default=None)
     ap.add_argument("--detail", type=float, default=1.0)
@@ -34,6 +36,8 @@ def main():
     ap.add_argument("--out", default="gpurun_out/render.png")
     ap.add_argument("--curve", default=None, help="write the RMSE-vs-spp convergence curve (JSON) here")
     ap.add_argument("--compare", default=None, help="PNG to compare the tone-mapped result with (RMSE of 8-bit values / 255)")
+    ap.add_argument("--side-by-side", default=None, help="with --compare: write [render | reference] at the reference's size here")
+    ap.add_argument("--report", default=None, help="with --compare: write the numbers and the scene parameters as JSON here")
     args = ap.parse_args()
 
     from PIL import Image
@@ -47,6 +51,8 @@ def main():
         mesh, cam_kw = assets.GltfMeshLoader.load(args.glb), scenes.ATRIUM_CAMERA
     elif args.scene == "cornell":
         mesh, cam_kw = scenes.cornell(), scenes.CORNELL_CAMERA
+    elif args.scene == "cornell_ref":
+        mesh, cam_kw = scenes.cornell_ref(), scenes.CORNELL_REF_CAMERA
     else:
         mesh, cam_kw = scenes.atrium(args.detail), scenes.ATRIUM_CAMERA
     sky = assets.read_exr(args.exr) if args.exr else (scenes.sky(2048, 1024) if args.scene == "atrium" or args.glb else None)
@@ -79,8 +85,26 @@ def main():
         Path(args.curve).write_text(json.dumps({"size": [W, H], "spp_per_pass": args.spp, "passes": args.passes, "curve": curve}, indent=1))
         print("convergence:", ", ".join(f"{c['spp']}spp {c['rmse_vs_final']:.4f}" for c in curve[:: max(1, len(curve) // 8)]))
     if args.compare:
-        ref = np.array(Image.open(args.compare).convert("RGB").resize((W, H)), np.float64) / 255
-        print(f"informational RMSE vs {args.compare} (8-bit, display referred, different scene / renderer): {np.sqrt(np.mean((img8 / 255.0 - ref) ** 2)):.4f}")
+        refimg = Image.open(args.compare).convert("RGB")
+        rw, rh = refimg.size
+        if W % rw == 0 and H % rh == 0 and W // rw == H // rh:  # box-filter the render down to the reference's size
+            k = W // rw
+            mine = img8.reshape(rh, k, rw, k, 3).astype(np.float64).mean((1, 3)) / 255.0
+            ref = np.array(refimg, np.float64) / 255
+        else:
+            mine, ref = img8 / 255.0, np.array(refimg.resize((W, H)), np.float64) / 255
+        rmse = float(np.sqrt(np.mean((mine - ref) ** 2)))
+        print(f"informational RMSE vs {args.compare} (8-bit, display referred, another renderer): {rmse:.4f}")
+        if args.side_by_side:
+            Image.fromarray(np.concatenate([(mine * 255 + 0.5).astype(np.uint8), (ref * 255 + 0.5).astype(np.uint8)], 1)).save(args.side_by_side)
+        if args.report:
+            Path(args.report).write_text(json.dumps({
+                "scene": args.scene, "render": {"size": [W, H], "spp": args.spp * args.passes, "bounces": args.bounces, "flags": flags},
+                "camera": {k: (list(v) if isinstance(v, tuple) else v) for k, v in cam_kw.items()},
+                "light_emission": scenes.CORNELL_REF_EMISSION if args.scene == "cornell_ref" else None,
+                "compare": args.compare, "compared_at": [int(mine.shape[1]), int(mine.shape[0])], "rmse_8bit": rmse,
+                "note": "informational: the reference image is a Blender-Cycles render (100 spp, its own view transform); scene rebuilt from the "
+                        "eight cubes / materials of the reference's processed box.glb, placements and emission fitted to the image"}, indent=1))
     pt.close()
 
 
