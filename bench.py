@@ -295,7 +295,7 @@ def main():
     # ---- measured fabric-side traffic.  HBM-side bytes cannot be counted from inside this process: they come from separate
     # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command (tools/profile_round.sh), summarised by
     # tools/summarize_profile.py into profiles/*_traffic.json.  Quoted only for the default workload they were collected on AND
-    # only while the kernel's average duration in that profile agrees with this run's within 15 % (a stale profile is not evidence).
+    # only while the kernel's average duration in that profile agrees with this run's within 5 % (a stale profile is not evidence).
     prof = None
     tfiles = sorted((ROOT / "profiles").glob("r*_traffic.json"))
     if tfiles and default_workload and world == 1:
@@ -311,7 +311,7 @@ def main():
 
     def hbm_side(entry, live_avg_ms):
         """{traffic, traffic_raw, achieved GB/s, frac} from a profile entry, or Nones when absent / stale."""
-        if not entry or not entry.get("avg_ms") or live_avg_ms <= 0 or abs(entry["avg_ms"] / live_avg_ms - 1.0) > 0.15:
+        if not entry or not entry.get("avg_ms") or live_avg_ms <= 0 or abs(entry["avg_ms"] / live_avg_ms - 1.0) > 0.05:
             return {"traffic": None, "traffic_raw": None, "achieved": None, "frac": None, "stale_or_missing": True}
         t = entry["hbm_bytes_per_launch"]
         g = t / (live_avg_ms * 1e-3) / 1e9
@@ -340,7 +340,7 @@ def main():
     shade_traffic = None
     if sh_first and sh_later and sh_first.get("avg_ms") and sh_later.get("avg_ms"):
         prof_shade_ms = sh_first["avg_ms"] + sh_later["avg_ms"] * (args.bounces - 1)
-        if shade_ms > 0 and abs(prof_shade_ms / shade_ms - 1.0) <= 0.15:
+        if shade_ms > 0 and abs(prof_shade_ms / shade_ms - 1.0) <= 0.05:
             shade_traffic = sh_first["hbm_bytes_per_launch"] + sh_later["hbm_bytes_per_launch"] * (args.bounces - 1)
     roofline = {
         "kernel": dom_name, "bound": "hbm", "peak": peak, "unit": "GB/s",

@@ -138,7 +138,9 @@ int rt3_set_option(rt3_ctx *ctx, int option, int64_t value);
 int rt3_scene_set_vertices(rt3_ctx *ctx, const float *interleaved_p_n_t, uint32_t n_vertices); /* Vertex, assets/mod.rs:127-133 */
 int rt3_scene_set_indices(rt3_ctx *ctx, const uint32_t *indices, uint32_t n_indices);
 int rt3_scene_set_geometry(rt3_ctx *ctx, const rt3_geometry_info *infos, const uint32_t *prim_counts, uint32_t n);
-int rt3_scene_set_sky(rt3_ctx *ctx, const float *rgb, uint32_t width, uint32_t height);     /* main.rs:94 (commented skybox2.exr) */
+/* equirect sky (main.rs:94, the commented skybox2.exr): finite, non-negative radiance.  Stored as RGB9E5 (packing.slang:99-162, the
+ * format the reference's G-buffer keeps emissive in; values above 65408 clamp): every sky lookup reads the de-quantised texel */
+int rt3_scene_set_sky(rt3_ctx *ctx, const float *rgb, uint32_t width, uint32_t height);
 int rt3_scene_set_bluenoise(rt3_ctx *ctx, const uint8_t *rgba, uint32_t width, uint32_t height); /* resources/bluenoise.png */
 /* base-colour texture `index` (dense indices 0..n-1): RGBA8 with sRGB-encoded colour, sampled bilinearly with repeat
  * addressing at mip 0 like Textures[i].SampleLevel(uvs, 0.0) (hit_logic.slang:31-33; bindless set 2, bindless/mod.rs:38-77) */
@@ -150,7 +152,9 @@ int rt3_accel_build(rt3_ctx *ctx, uint32_t *out_handle);
 /* introspection for parity tests: copy the BVH to the host (nodes: n_nodes x node_bytes (64 | 128), tris: n_tris x 48 B) */
 int rt3_accel_info(rt3_ctx *ctx, uint32_t *n_nodes, uint32_t *n_tris, uint32_t *max_depth, uint32_t *node_bytes);
 int rt3_accel_download(rt3_ctx *ctx, void *nodes, size_t nodes_bytes, void *tris, size_t tris_bytes);
-int rt3_sky_download(rt3_ctx *ctx, float *cdf_cond, float *cdf_marg, float *pdf_uv); /* w*h, h, w*h floats */
+/* sky tables for parity tests (any pointer may be NULL): per-row alias words q16 | alias << 16 (w*h), RGB9E5 texels (w*h),
+ * marginal CDF (h), realised (u,v) density (w*h) */
+int rt3_sky_download(rt3_ctx *ctx, uint32_t *alias, uint32_t *texels_rgb9e5, float *cdf_marg, float *pdf_uv);
 
 /* ---- resources: RenderGraph::image / buffer / import (render_graph/mod.rs:422-483) ---- */
 int rt3_buffer_create(rt3_ctx *ctx, size_t bytes, uint32_t *out_handle);

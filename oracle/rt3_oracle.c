@@ -409,7 +409,9 @@ struct orc_scene {
     uint64_t *codes;
     /* sky */
     float *sky; uint32_t sky_w, sky_h;
-    float *cdf_cond, *cdf_marg, *pdf_uv;
+    float *cdf_marg, *pdf_uv;      /* marginal CDF over rows; realised (u,v)-density per texel */
+    uint32_t *sky_alias;           /* per texel: keep-threshold q16 | alias column << 16 (one alias table per row) */
+    uint32_t *sky_q;               /* per texel: the RGB9E5 word the radiance is stored as */
     /* blue noise */
     uint8_t *bn; uint32_t bn_w, bn_h;
     /* base-colour textures (RGBA8, sRGB-encoded colour), hit_logic.slang:31-33 */
@@ -526,7 +528,7 @@ void orc_scene_destroy(orc_scene *s) {
     if (!s) return;
     accel_free(s);
     free(s->verts); free(s->indices); free(s->geoms); free(s->prim_counts); free(s->first_prim); free(s->prim_geom);
-    free(s->sky); free(s->cdf_cond); free(s->cdf_marg); free(s->pdf_uv); free(s->bn);
+    free(s->sky); free(s->sky_alias); free(s->sky_q); free(s->cdf_marg); free(s->pdf_uv); free(s->bn);
     for (uint32_t i = 0; i < s->n_tex; i++) free(s->tex[i]);
     free(s->tex); free(s->tex_w); free(s->tex_h);
     free(s);
@@ -600,46 +602,81 @@ static void texture_sample(const orc_scene *s, uint32_t index, float u, float v,
 }
 /* math.slang:119-122 */
 static float luminance3(const float c[3]) { return c[0] * 0.299f + c[1] * 0.587f + c[2] * 0.114f; }
-/* [north_star] sky importance tables: f = luminance * sin(theta) per texel, conditional CDF per row, marginal CDF
- * over rows, pdf in (u,v) space.  Built in double, stored as float. */
+/* [north_star] sky storage and importance tables.
+ *  - Radiance is STORED as RGB9E5 (packing.slang:99-162, the format the reference's G-buffer keeps emissive in): every sky lookup
+ *    -- background, escaped paths, light samples -- reads the de-quantised value, and the tables below are built from it.
+ *  - f = (luminance + 1e-6) * sin(theta) per texel.  Rows: marginal CDF (inverted by search).  Inside a row: ONE alias table
+ *    (Vose 1991) -- a light sample costs one table word instead of a CDF search: entry k = {q16, alias}: keep column k if
+ *    xi < Q = (q16 + 1) / 65536, else take column `alias` (xi = frac(u * w)).  Q is 16-bit, so the probability a column REALLY
+ *    has is (Q[x] + sum over j with alias[j] = x of (1 - Q[j])) / w; pdf_uv stores that realised density, which keeps the
+ *    estimator exact for the quantised table (Q >= 2^-16: no column of a row is unreachable).
+ *    All in double, fixed order; librt3 builds the identical tables (rt3_scene_set_sky). */
 int orc_scene_set_sky(orc_scene *s, const float *rgb, uint32_t w, uint32_t h) {
     for (size_t i = 0; i < (size_t)w * h * 3; i++) /* same contract as rt3_scene_set_sky: finite, non-negative radiance */
         if (!(rgb[i] >= 0.0f && rgb[i] <= 3.4028234663852886e38f)) return -1;
-    free(s->sky); free(s->cdf_cond); free(s->cdf_marg); free(s->pdf_uv);
+    if (w > 65535u || h > 65535u) return -1;
+    free(s->sky); free(s->sky_alias); free(s->sky_q); free(s->cdf_marg); free(s->pdf_uv);
     size_t n = (size_t)w * h;
     s->sky = (float *)malloc(n * 12);
-    memcpy(s->sky, rgb, n * 12);
+    s->sky_q = (uint32_t *)malloc(n * 4);
+    for (size_t i = 0; i < n; i++) {
+        s->sky_q[i] = orc_float3_to_rgb9e5(rgb + 3 * i);
+        orc_rgb9e5_to_float3(s->sky_q[i], s->sky + 3 * i);
+    }
     s->sky_w = w; s->sky_h = h;
-    s->cdf_cond = (float *)malloc(n * 4);
+    s->sky_alias = (uint32_t *)malloc(n * 4);
     s->pdf_uv = (float *)malloc(n * 4);
     s->cdf_marg = (float *)malloc((size_t)h * 4);
     double *rowsum = (double *)malloc((size_t)h * 8), total = 0.0;
+    double *f = (double *)malloc((size_t)w * 8), *sc = (double *)malloc((size_t)w * 8), *real = (double *)malloc((size_t)w * 8);
+    uint32_t *small = (uint32_t *)malloc((size_t)w * 4), *large = (uint32_t *)malloc((size_t)w * 4);
     for (uint32_t y = 0; y < h; y++) {
         double st = sin(3.14159265358979323846 * ((double)y + 0.5) / (double)h), acc = 0.0;
         for (uint32_t x = 0; x < w; x++) {
-            double f = ((double)luminance3(rgb + 3 * ((size_t)y * w + x)) + 1e-6) * st;
-            s->pdf_uv[(size_t)y * w + x] = (float)f; /* temporarily the unnormalised density */
-            acc += f;
-            s->cdf_cond[(size_t)y * w + x] = (float)acc; /* normalised below */
+            f[x] = ((double)luminance3(s->sky + 3 * ((size_t)y * w + x)) + 1e-6) * st;
+            acc += f[x];
         }
         rowsum[y] = acc;
         total += acc;
+        /* Vose's alias method, deterministic: columns enter the two stacks in ascending order, both are popped from the top */
+        uint32_t ns = 0, nl = 0;
+        uint32_t *al = s->sky_alias + (size_t)y * w;
+        for (uint32_t x = 0; x < w; x++) {
+            sc[x] = f[x] * (double)w / acc;
+            if (sc[x] < 1.0) small[ns++] = x; else large[nl++] = x;
+        }
+        for (uint32_t x = 0; x < w; x++) al[x] = 65535u | (x << 16); /* default: always keep (also what is left on a stack at the end) */
+        while (ns && nl) {
+            uint32_t a = small[--ns], g = large[--nl];
+            double q = sc[a] * 65536.0;
+            int64_t q16 = (int64_t)floor(q + 0.5) - 1;
+            q16 = q16 < 0 ? 0 : (q16 > 65535 ? 65535 : q16);
+            al[a] = (uint32_t)q16 | (g << 16);
+            sc[g] = (sc[g] + sc[a]) - 1.0;
+            if (sc[g] < 1.0) small[ns++] = g; else large[nl++] = g;
+        }
+        /* realised column probabilities of the quantised table */
+        for (uint32_t x = 0; x < w; x++) real[x] = 0.0;
+        for (uint32_t x = 0; x < w; x++) {
+            double Q = (double)((al[x] & 0xFFFFu) + 1u) / 65536.0;
+            real[x] += Q;
+            real[al[x] >> 16] += 1.0 - Q;
+        }
+        for (uint32_t x = 0; x < w; x++) s->pdf_uv[(size_t)y * w + x] = (float)real[x]; /* x row probability x h below */
     }
     double acc = 0.0;
     for (uint32_t y = 0; y < h; y++) {
-        float inv = (float)(1.0 / rowsum[y]);
-        for (uint32_t x = 0; x < w; x++) s->cdf_cond[(size_t)y * w + x] *= inv;
-        s->cdf_cond[(size_t)y * w + w - 1] = 1.0f;
         acc += rowsum[y];
         s->cdf_marg[y] = (float)(acc / total);
+        const double rowp = rowsum[y] / total * (double)h;
+        for (uint32_t x = 0; x < w; x++) s->pdf_uv[(size_t)y * w + x] = (float)((double)s->pdf_uv[(size_t)y * w + x] * rowp);
     }
     s->cdf_marg[h - 1] = 1.0f;
-    float norm = (float)((double)w * (double)h / total);
-    for (size_t i = 0; i < n; i++) s->pdf_uv[i] *= norm;
-    free(rowsum);
+    free(rowsum); free(f); free(sc); free(real); free(small); free(large);
     return 0;
 }
-const float *orc_sky_cdf_cond(const orc_scene *s) { return s->cdf_cond; }
+const uint32_t *orc_sky_alias(const orc_scene *s) { return s->sky_alias; }
+const uint32_t *orc_sky_texels(const orc_scene *s) { return s->sky_q; }
 const float *orc_sky_cdf_marg(const orc_scene *s) { return s->cdf_marg; }
 const float *orc_sky_pdf_uv(const orc_scene *s) { return s->pdf_uv; }
 
@@ -1332,10 +1369,19 @@ static void sky_sample(const orc_scene *s, float u0, float u1, float dir[3], flo
     uint32_t y = cdf_find(s->cdf_marg, H, u0);
     float lo = y > 0 ? s->cdf_marg[y - 1] : 0.0f, hi = s->cdf_marg[y];
     float dv = hi > lo ? (u0 - lo) / (hi - lo) : 0.5f;
-    const float *row = s->cdf_cond + (size_t)y * W;
-    uint32_t x = cdf_find(row, W, u1);
-    lo = x > 0 ? row[x - 1] : 0.0f; hi = row[x];
-    float du = hi > lo ? (u1 - lo) / (hi - lo) : 0.5f;
+    /* the row's alias table: cell k = floor(u1 w), xi = frac(u1 w) decides between column k and its alias and is then
+     * stretched back to [0, 1) as the position inside the chosen texel */
+    float sx = u1 * (float)W;
+    uint32_t k = (uint32_t)sx;
+    k = k > W - 1 ? W - 1 : k;
+    float xi = sx - (float)k;
+    xi = xi < 0.99999994f ? xi : 0.99999994f;
+    const uint32_t e = s->sky_alias[(size_t)y * W + k];
+    const float Q = (float)((e & 0xFFFFu) + 1u) * (1.0f / 65536.0f);
+    const int keep = xi < Q;
+    uint32_t x = keep ? k : (e >> 16);
+    float du = keep ? xi / Q : (xi - Q) / (1.0f - Q);
+    du = du < 0.99999994f ? du : 0.99999994f;
     float u = ((float)x + du) / (float)W, v = ((float)y + dv) / (float)H;
     float st, ct, s2, c2;
     orc_sincos_2pi(v * 0.5f, &st, &ct);

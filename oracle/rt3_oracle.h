@@ -121,7 +121,8 @@ const float *orc_accel_tris(const orc_scene *s);   /* n_tris  x 12 words (48 B);
 const uint64_t *orc_accel_codes(const orc_scene *s);
 uint32_t orc_accel_max_depth(const orc_scene *s);
 /* sky tables (for parity checks against the product) */
-const float *orc_sky_cdf_cond(const orc_scene *s);
+const uint32_t *orc_sky_alias(const orc_scene *s);  /* w*h words: q16 | alias column << 16 */
+const uint32_t *orc_sky_texels(const orc_scene *s); /* w*h RGB9E5 words */
 const float *orc_sky_cdf_marg(const orc_scene *s);
 const float *orc_sky_pdf_uv(const orc_scene *s);
 

@@ -92,7 +92,7 @@ def load():
         "rt3_accel_build": (i32, [vp, pu32]),
         "rt3_accel_info": (i32, [vp, pu32, pu32, pu32, pu32]),
         "rt3_accel_download": (i32, [vp, vp, sz, vp, sz]),
-        "rt3_sky_download": (i32, [vp, vp, vp, vp]),
+        "rt3_sky_download": (i32, [vp, vp, vp, vp, vp]),
         "rt3_buffer_create": (i32, [vp, sz, pu32]),
         "rt3_image_create": (i32, [vp, u32, u32, u32, pu32]),
         "rt3_image_import": (i32, [vp, vp, u32, u32, u32, pu32]),

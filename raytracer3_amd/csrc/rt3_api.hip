@@ -72,9 +72,10 @@ struct rt3_ctx {
     GeometryInfoDev* d_geoms = nullptr;
     uint32_t n_geoms = 0, n_prims = 0;
     uint32_t *d_prim_geom = nullptr, *d_first_prim = nullptr;
-    float *d_sky = nullptr, *d_cdf_cond = nullptr, *d_cdf_marg = nullptr;
-    uint32_t *d_guide_cond = nullptr, *d_guide_marg = nullptr;
-    uint32_t sky_w = 0, sky_h = 0;
+    uint2* d_sky = nullptr;  // 8-byte texels {RGB9E5, pdf_uv} in 4 x 4 tiles
+    float* d_cdf_marg = nullptr;
+    uint32_t *d_sky_alias = nullptr, *d_guide_marg = nullptr;
+    uint32_t sky_w = 0, sky_h = 0, sky_wt = 0;
     uint8_t* d_bn = nullptr;
     uint32_t bn_w = 0, bn_h = 0;
     uint64_t bn_stamp = 0;  // bumped by every rt3_scene_set_bluenoise
@@ -225,13 +226,13 @@ SceneDev scene_dev(const rt3_ctx* c) {
     s.prim_geom = c->d_prim_geom;
     s.first_prim = c->d_first_prim;
     s.tri_shade = c->bvh.tri_shade;
-    s.guide_cond = c->d_guide_cond;
     s.guide_marg = c->d_guide_marg;
     s.sky = c->d_sky;
-    s.cdf_cond = c->d_cdf_cond;
+    s.sky_alias = c->d_sky_alias;
     s.cdf_marg = c->d_cdf_marg;
     s.sky_w = c->sky_w;
     s.sky_h = c->sky_h;
+    s.sky_wt = c->sky_wt;
     s.bluenoise = c->d_bn;
     s.bn_w = c->bn_w;
     s.bn_h = c->bn_h;
@@ -691,8 +692,8 @@ void rt3_destroy(rt3_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     dev_free(c->d_verts); dev_free(c->d_indices); dev_free(c->d_geoms); dev_free(c->d_prim_geom); dev_free(c->d_first_prim);
     dev_free(c->d_tex_pixels); dev_free(c->d_tex_table); dev_free(c->d_srgb_lut);
-    dev_free(c->d_sky); dev_free(c->d_cdf_cond); dev_free(c->d_cdf_marg); dev_free(c->d_bn);
-    dev_free(c->bvh.nodes); dev_free(c->bvh.tris); dev_free(c->bvh.tri_shade); dev_free(c->d_guide_cond); dev_free(c->d_guide_marg);
+    dev_free(c->d_sky); dev_free(c->d_sky_alias); dev_free(c->d_cdf_marg); dev_free(c->d_bn);
+    dev_free(c->bvh.nodes); dev_free(c->bvh.tris); dev_free(c->bvh.tri_shade); dev_free(c->d_guide_marg);
     for (auto& r : c->resources)
         if (r.owned && r.ptr) (void)hipFree(r.ptr);
     for (auto& p : c->pixlists) {
@@ -843,93 +844,138 @@ int rt3_scene_set_geometry(rt3_ctx* c, const rt3_geometry_info* g, const uint32_
     c->accel_built = false;
     return RT3_OK;
 }
-// sky importance tables (north_star): f = (luminance + 1e-6) * sin(theta); conditional CDF per row, marginal CDF over
-// rows, pdf in (u,v).  Accumulated in double on the host, stored as float.
+// Sky storage and importance tables (north_star; the oracle's orc_scene_set_sky has the definitions and is built by the same
+// arithmetic, in double, in the same order): radiance stored as RGB9E5 (packing.slang:99-162), marginal CDF over rows, one alias
+// table per row with 16-bit keep-thresholds, pdf_uv = the density the quantised tables really realise.
+static uint32_t host_rgb9e5(const float* c) {  // packing.slang:99-144 == rt3_device.hpp float3_to_rgb9e5
+    auto bits = [](float f) { uint32_t u; memcpy(&u, &f, 4); return u; };
+    auto from_bits = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+    const float mx = (511.0f / 512.0f) * 65536.0f;
+    auto clampf = [&](float v) { v = v > 0.0f ? v : 0.0f; return v < mx ? v : mx; };
+    const float rc = clampf(c[0]), gc = clampf(c[1]), bc = clampf(c[2]);
+    const float m1 = gc > bc ? gc : bc, maxrgb = rc > m1 ? rc : m1;
+    const int fl2 = (int)((bits(maxrgb) & 0x7F800000u) >> 23) - 127;
+    int exp_shared = (fl2 > -16 ? fl2 : -16) + 1 + 15;
+    float denom = from_bits((uint32_t)(exp_shared - 15 - 9 + 127) << 23);
+    const int maxm = (int)std::floor(maxrgb / denom + 0.5f);
+    if (maxm == 512) {
+        denom *= 2.0f;
+        exp_shared += 1;
+    }
+    const int rm = (int)std::floor(rc / denom + 0.5f), gm = (int)std::floor(gc / denom + 0.5f), bm = (int)std::floor(bc / denom + 0.5f);
+    return ((uint32_t)rm << 23) | ((uint32_t)gm << 14) | ((uint32_t)bm << 5) | (uint32_t)exp_shared;
+}
+static void host_rgb9e5_decode(uint32_t v, float* c) {  // packing.slang:146-162
+    const uint32_t sb = (uint32_t)((int)(v & 31u) - 24 + 127) << 23;
+    float scale;
+    memcpy(&scale, &sb, 4);
+    c[0] = (float)((v >> 23) & 511u) * scale;
+    c[1] = (float)((v >> 14) & 511u) * scale;
+    c[2] = (float)((v >> 5) & 511u) * scale;
+}
 int rt3_scene_set_sky(rt3_ctx* c, const float* rgb, uint32_t w, uint32_t h) {
     if (!c || !rgb || !w || !h) return fail(c, RT3_E_INVALID, "sky NULL / empty");
     if (w > 65535 || h > 65535) return fail(c, RT3_E_INVALID, "sky larger than 65535 texels per side");
     HIPC(c, hipSetDevice(c->device));
     const size_t n = (size_t)w * h;
-    for (size_t i = 0; i < 3 * n; i++)  // a NaN or negative texel would poison the sampling tables (every CDF entry after it)
+    for (size_t i = 0; i < 3 * n; i++)  // a NaN or negative texel would poison the sampling tables
         if (!(rgb[i] >= 0.0f && rgb[i] <= 3.4028234663852886e38f))
             return fail(c, RT3_E_INVALID, "sky texel " + std::to_string(i / 3) + " is negative or not finite (clamp the image before uploading it)");
-    std::vector<float> cond(n), pdf(n), marg(h);
-    std::vector<double> rows(h);
+    std::vector<uint32_t> texq(n), alias(n);
+    std::vector<float> pdf(n), marg(h);
+    std::vector<double> rows(h), f(w), sc(w), real(w);
+    std::vector<uint32_t> small(w), large(w);
     double total = 0.0;
     for (uint32_t y = 0; y < h; y++) {
         const double st = std::sin(3.14159265358979323846 * ((double)y + 0.5) / (double)h);
         double acc = 0.0;
         for (uint32_t x = 0; x < w; x++) {
-            const float* p = rgb + 3 * ((size_t)y * w + x);
+            const size_t i = (size_t)y * w + x;
+            texq[i] = host_rgb9e5(rgb + 3 * i);
+            float p[3];
+            host_rgb9e5_decode(texq[i], p);
             const float lum = p[0] * 0.299f + p[1] * 0.587f + p[2] * 0.114f;  // luminance(), math.slang:119-122
-            const double f = ((double)lum + 1e-6) * st;
-            pdf[(size_t)y * w + x] = (float)f;
-            acc += f;
-            cond[(size_t)y * w + x] = (float)acc;
+            f[x] = ((double)lum + 1e-6) * st;
+            acc += f[x];
         }
         rows[y] = acc;
         total += acc;
+        uint32_t ns = 0, nl = 0;
+        uint32_t* al = alias.data() + (size_t)y * w;
+        for (uint32_t x = 0; x < w; x++) {
+            sc[x] = f[x] * (double)w / acc;
+            if (sc[x] < 1.0) small[ns++] = x;
+            else large[nl++] = x;
+        }
+        for (uint32_t x = 0; x < w; x++) al[x] = 65535u | (x << 16);
+        while (ns && nl) {  // Vose's alias method; both stacks filled in ascending column order and popped from the top
+            const uint32_t a = small[--ns], g = large[--nl];
+            const double q = sc[a] * 65536.0;
+            int64_t q16 = (int64_t)std::floor(q + 0.5) - 1;
+            q16 = q16 < 0 ? 0 : (q16 > 65535 ? 65535 : q16);
+            al[a] = (uint32_t)q16 | (g << 16);
+            sc[g] = (sc[g] + sc[a]) - 1.0;
+            if (sc[g] < 1.0) small[ns++] = g;
+            else large[nl++] = g;
+        }
+        for (uint32_t x = 0; x < w; x++) real[x] = 0.0;
+        for (uint32_t x = 0; x < w; x++) {
+            const double Q = (double)((al[x] & 0xFFFFu) + 1u) / 65536.0;
+            real[x] += Q;
+            real[al[x] >> 16] += 1.0 - Q;
+        }
+        for (uint32_t x = 0; x < w; x++) pdf[(size_t)y * w + x] = (float)real[x];
     }
     double run = 0.0;
     for (uint32_t y = 0; y < h; y++) {
-        const float inv = (float)(1.0 / rows[y]);
-        for (uint32_t x = 0; x < w; x++) cond[(size_t)y * w + x] *= inv;
-        cond[(size_t)y * w + w - 1] = 1.0f;
         run += rows[y];
         marg[y] = (float)(run / total);
+        const double rowp = rows[y] / total * (double)h;
+        for (uint32_t x = 0; x < w; x++) pdf[(size_t)y * w + x] = (float)((double)pdf[(size_t)y * w + x] * rowp);
     }
     marg[h - 1] = 1.0f;
-    const float norm = (float)((double)w * (double)h / total);
-    for (size_t i = 0; i < n; i++) pdf[i] *= norm;
-    // guide tables: guide[k] = first index with cdf > k / n, so a lookup of u (cell k = floor(u n)) starts inside
+    // guide table of the marginal CDF: guide[k] = first index with cdf > k / n, so a lookup of u (cell k = floor(u n)) starts inside
     // [guide[k-1], guide[k+1]].  Stored per cell as one word lo | hi << 16 (hi clamped to n-1): one load instead of two.
-    auto build_guide = [](const float* cdf, uint32_t cnt, uint32_t* g2) {
-        std::vector<uint32_t> g(cnt + 1);
+    std::vector<uint32_t> gmarg(h);
+    {
+        std::vector<uint32_t> g(h + 1);
         uint32_t i = 0;
-        for (uint32_t k = 0; k <= cnt; k++) {
-            const float thr = (float)k / (float)cnt;
-            while (i < cnt - 1 && !(cdf[i] > thr)) i++;
+        for (uint32_t k = 0; k <= h; k++) {
+            const float thr = (float)k / (float)h;
+            while (i < h - 1 && !(marg[i] > thr)) i++;
             g[k] = i;
         }
-        for (uint32_t k = 0; k < cnt; k++) {
-            const uint32_t lo = g[k > 0 ? k - 1 : 0], hi = g[k + 1] > cnt - 1 ? cnt - 1 : g[k + 1];
-            g2[k] = lo | (hi << 16);
+        for (uint32_t k = 0; k < h; k++) {
+            const uint32_t lo = g[k > 0 ? k - 1 : 0], hi = g[k + 1] > h - 1 ? h - 1 : g[k + 1];
+            gmarg[k] = lo | (hi << 16);
         }
-    };
-    // CDFs are stored with one leading 0 and three trailing pads (2.0 > any u): cdfp[i + 1] = cdf[i], so that
-    // {cdf[i-1], cdf[i], cdf[i+1], cdf[i+2]} is ONE 16-byte load at cdfp + i for every i (row stride w + 4).
-    std::vector<uint32_t> gcond(n), gmarg(h);
-    for (uint32_t y = 0; y < h; y++) build_guide(cond.data() + (size_t)y * w, w, gcond.data() + (size_t)y * w);
-    build_guide(marg.data(), h, gmarg.data());
-    std::vector<float> condp((size_t)h * (w + 4)), margp((size_t)h + 4);
-    for (uint32_t y = 0; y < h; y++) {
-        float* r = condp.data() + (size_t)y * (w + 4);
-        r[0] = 0.0f;
-        std::memcpy(r + 1, cond.data() + (size_t)y * w, (size_t)w * 4);
-        r[w + 1] = r[w + 2] = r[w + 3] = 2.0f;
     }
+    // the marginal CDF is stored with one leading 0 and three trailing pads (2.0 > any u): cdfp[i + 1] = cdf[i], so that
+    // {cdf[i-1], cdf[i], cdf[i+1], cdf[i+2]} is ONE 16-byte load at cdfp + i for every i
+    std::vector<float> margp((size_t)h + 4);
     margp[0] = 0.0f;
     std::memcpy(margp.data() + 1, marg.data(), (size_t)h * 4);
     margp[h + 1] = margp[h + 2] = margp[h + 3] = 2.0f;
-    if (int r = dev_alloc(c, &c->d_guide_cond, gcond.size())) return r;
+    // texels in 4 x 4 tiles of 128 bytes; ragged edges are padded (never addressed: lookups wrap / clamp to [0, w) x [0, h))
+    const uint32_t wt = (w + 3) / 4, ht = (h + 3) / 4;
+    std::vector<uint2> tiled((size_t)wt * ht * 16, make_uint2(0u, 0u));
+    for (uint32_t y = 0; y < h; y++)
+        for (uint32_t x = 0; x < w; x++) {
+            uint32_t pb;
+            memcpy(&pb, &pdf[(size_t)y * w + x], 4);
+            tiled[((size_t)(y >> 2) * wt + (x >> 2)) * 16 + (((y & 3u) << 2) | (x & 3u))] = make_uint2(texq[(size_t)y * w + x], pb);
+        }
     if (int r = dev_alloc(c, &c->d_guide_marg, gmarg.size())) return r;
-    HIPC(c, hipMemcpy(c->d_guide_cond, gcond.data(), gcond.size() * 4, hipMemcpyHostToDevice));
-    HIPC(c, hipMemcpy(c->d_guide_marg, gmarg.data(), gmarg.size() * 4, hipMemcpyHostToDevice));
-    std::vector<float> sky4(4 * n);  // {r, g, b, pdf_uv} per texel
-    for (size_t i = 0; i < n; i++) {
-        sky4[4 * i] = rgb[3 * i];
-        sky4[4 * i + 1] = rgb[3 * i + 1];
-        sky4[4 * i + 2] = rgb[3 * i + 2];
-        sky4[4 * i + 3] = pdf[i];
-    }
-    if (int r = dev_alloc(c, &c->d_sky, 4 * n)) return r;
-    if (int r = dev_alloc(c, &c->d_cdf_cond, condp.size())) return r;
+    if (int r = dev_alloc(c, &c->d_sky_alias, alias.size())) return r;
+    if (int r = dev_alloc(c, &c->d_sky, tiled.size())) return r;
     if (int r = dev_alloc(c, &c->d_cdf_marg, margp.size())) return r;
-    HIPC(c, hipMemcpy(c->d_sky, sky4.data(), n * 16, hipMemcpyHostToDevice));
-    HIPC(c, hipMemcpy(c->d_cdf_cond, condp.data(), condp.size() * 4, hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(c->d_guide_marg, gmarg.data(), gmarg.size() * 4, hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(c->d_sky_alias, alias.data(), alias.size() * 4, hipMemcpyHostToDevice));
+    HIPC(c, hipMemcpy(c->d_sky, tiled.data(), tiled.size() * 8, hipMemcpyHostToDevice));
     HIPC(c, hipMemcpy(c->d_cdf_marg, margp.data(), margp.size() * 4, hipMemcpyHostToDevice));
     c->sky_w = w;
     c->sky_h = h;
+    c->sky_wt = wt;
     return RT3_OK;
 }
 int rt3_scene_set_bluenoise(rt3_ctx* c, const uint8_t* rgba, uint32_t w, uint32_t h) {
@@ -956,20 +1002,20 @@ int rt3_scene_set_texture(rt3_ctx* c, uint32_t index, const uint8_t* rgba, uint3
     c->tex_dirty = true;
     return RT3_OK;
 }
-int rt3_sky_download(rt3_ctx* c, float* cond, float* marg, float* pdf) {
+int rt3_sky_download(rt3_ctx* c, uint32_t* alias, uint32_t* texels, float* marg, float* pdf) {
     if (!c || !c->d_sky) return fail(c, RT3_E_STATE, "no sky set");
-    size_t n = (size_t)c->sky_w * c->sky_h;
-    // the device copies are padded (one leading 0, three trailing pads per CDF): strip the padding
-    if (cond) {
-        std::vector<float> padded((size_t)c->sky_h * (c->sky_w + 4));
-        HIPC(c, hipMemcpy(padded.data(), c->d_cdf_cond, padded.size() * 4, hipMemcpyDeviceToHost));
-        for (uint32_t y = 0; y < c->sky_h; y++) std::memcpy(cond + (size_t)y * c->sky_w, padded.data() + (size_t)y * (c->sky_w + 4) + 1, (size_t)c->sky_w * 4);
-    }
-    if (marg) HIPC(c, hipMemcpy(marg, c->d_cdf_marg + 1, (size_t)c->sky_h * 4, hipMemcpyDeviceToHost));
-    if (pdf) {  // .w of every texel
-        std::vector<float> sky4(4 * n);
-        HIPC(c, hipMemcpy(sky4.data(), c->d_sky, n * 16, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < n; i++) pdf[i] = sky4[4 * i + 3];
+    const uint32_t w = c->sky_w, h = c->sky_h, wt = c->sky_wt, ht = (h + 3) / 4;
+    if (alias) HIPC(c, hipMemcpy(alias, c->d_sky_alias, (size_t)w * h * 4, hipMemcpyDeviceToHost));
+    if (marg) HIPC(c, hipMemcpy(marg, c->d_cdf_marg + 1, (size_t)h * 4, hipMemcpyDeviceToHost));  // strip the padding
+    if (texels || pdf) {  // un-tile
+        std::vector<uint2> tiled((size_t)wt * ht * 16);
+        HIPC(c, hipMemcpy(tiled.data(), c->d_sky, tiled.size() * 8, hipMemcpyDeviceToHost));
+        for (uint32_t y = 0; y < h; y++)
+            for (uint32_t x = 0; x < w; x++) {
+                const uint2 t = tiled[((size_t)(y >> 2) * wt + (x >> 2)) * 16 + (((y & 3u) << 2) | (x & 3u))];
+                if (texels) texels[(size_t)y * w + x] = t.x;
+                if (pdf) memcpy(&pdf[(size_t)y * w + x], &t.y, 4);
+            }
     }
     return RT3_OK;
 }

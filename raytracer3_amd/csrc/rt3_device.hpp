@@ -382,12 +382,11 @@ struct SceneDev {
     const float* srgb_lut;       // 256 entries: sRGB EOTF
     uint32_t n_tex;
     // sky
-    const float* sky;            // float4 texels {r, g, b, pdf_uv}
-    const float* cdf_cond;       // padded rows of sky_w + 4: {0, cdf[0..w-1], 2, 2, 2}
+    const uint2* sky;            // 8-byte texels {RGB9E5 radiance, pdf_uv}, in 4 x 4 texel tiles of 128 bytes = one cache line
+    const uint32_t* sky_alias;   // sky_w x sky_h words, row-major: per-row alias tables, q16 | alias column << 16
     const float* cdf_marg;       // padded: {0, cdf[0..h-1], 2, 2, 2}
-    const uint32_t* guide_cond;  // per row, sky_w cells: lo | hi << 16 = search bounds of the cell's answers
-    const uint32_t* guide_marg;  // sky_h cells
-    uint32_t sky_w, sky_h;
+    const uint32_t* guide_marg;  // sky_h cells: lo | hi << 16 = search bounds of the cell's answers
+    uint32_t sky_w, sky_h, sky_wt;  // sky_wt = tiles per tile row = ceil(sky_w / 4)
     const uint8_t* bluenoise;
     uint32_t bn_w, bn_h;
 };
@@ -449,8 +448,13 @@ RT3_DEV Surface hit_finish(const SceneDev& sc, const HitRecord& h, float bu, flo
 RT3_DEV Surface hit_info(const SceneDev& sc, uint32_t prim, float bu, float bv) { return hit_finish(sc, hit_fetch(sc, prim), bu, bv); }
 
 // ------------------------------------------------------------------------------------------------ sky (north_star)
-// Texels are stored as float4 {r, g, b, pdf_uv}: the importance-sampling density of a texel travels with its colour, so
-// a light sample / a miss costs no extra cache line for the pdf (the texel is always one of the four bilinear corners).
+// Texels are 8 bytes {RGB9E5 radiance, pdf_uv as f32}: the importance-sampling density of a texel travels with its colour (the
+// texel is always one of the four bilinear corners), and a 4 x 4 texel tile is exactly one 128-byte line -- the unit the fabric
+// moves whatever a lane asks for (profiles/r02_fetch_calibration.md): the 2 x 2 bilinear footprint costs 1.56 lines on average
+// instead of 2.25 with row-major 16-byte texels.
+RT3_DEV uint32_t sky_texel_index(const SceneDev& sc, int x, int y) {
+    return (((uint32_t)y >> 2) * sc.sky_wt + ((uint32_t)x >> 2)) * 16u + ((((uint32_t)y & 3u) << 2) | ((uint32_t)x & 3u));
+}
 RT3_DEV V3 sky_eval_pdf(const SceneDev& sc, float u, float v, int tx, int ty, float& pdf_texel) {
     int W = (int)sc.sky_w, H = (int)sc.sky_h;
     float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
@@ -461,13 +465,14 @@ RT3_DEV V3 sky_eval_pdf(const SceneDev& sc, float u, float v, int tx, int ty, fl
     x1 = wrap_index(x1, W);
     y0 = y0 < 0 ? 0 : (y0 > H - 1 ? H - 1 : y0);
     y1 = y1 < 0 ? 0 : (y1 > H - 1 ? H - 1 : y1);
-    const float4* sky = reinterpret_cast<const float4*>(sc.sky);
-    const float4 p00 = sky[(size_t)y0 * W + x0], p10 = sky[(size_t)y0 * W + x1], p01 = sky[(size_t)y1 * W + x0], p11 = sky[(size_t)y1 * W + x1];
+    const uint2 t00 = sc.sky[sky_texel_index(sc, x0, y0)], t10 = sc.sky[sky_texel_index(sc, x1, y0)];
+    const uint2 t01 = sc.sky[sky_texel_index(sc, x0, y1)], t11 = sc.sky[sky_texel_index(sc, x1, y1)];
     if (tx >= 0) {
         const bool in_x = tx == x0 || tx == x1, in_y = ty == y0 || ty == y1;
-        pdf_texel = ty == y0 ? (tx == x0 ? p00.w : p10.w) : (tx == x0 ? p01.w : p11.w);
-        if (!(in_x && in_y)) pdf_texel = sky[(size_t)ty * W + tx].w;  // not reached for (u, v) inside texel (tx, ty)
+        pdf_texel = __uint_as_float(ty == y0 ? (tx == x0 ? t00.y : t10.y) : (tx == x0 ? t01.y : t11.y));
+        if (!(in_x && in_y)) pdf_texel = __uint_as_float(sc.sky[sky_texel_index(sc, tx, ty)].y);  // not reached for (u, v) inside texel (tx, ty)
     }
+    const V3 p00 = rgb9e5_to_float3(t00.x), p10 = rgb9e5_to_float3(t10.x), p01 = rgb9e5_to_float3(t01.x), p11 = rgb9e5_to_float3(t11.x);
     const float a[3] = {p00.x, p00.y, p00.z}, bq[3] = {p10.x, p10.y, p10.z}, c[3] = {p01.x, p01.y, p01.z}, dq[3] = {p11.x, p11.y, p11.z};
     float o[3];
 #pragma unroll
@@ -498,7 +503,8 @@ RT3_DEV V3 sky_eval_and_pdf(const SceneDev& sc, float u, float v, float& pdf) {
 // The oracle's cdf_find -- first i with cdf[i] > u -- plus the bracket {cdf[i-1] (0 for i = 0), cdf[i]}, in two memory
 // round trips: the guide cell of u gives bounds [lo, hi] around the answer; when they are at most two apart (81-93 % of
 // the lookups on the bench sky) ONE unaligned 16-byte load {cdf[lo-1] .. cdf[lo+2]} of the padded CDF holds every
-// candidate and the bracket.  Wider cells fall back to the binary search.  These gathers are what k_shade is bound by.
+// candidate and the bracket.  Wider cells fall back to the binary search.  Used for the MARGINAL (row) table only, which
+// k_shade stages in LDS; inside a row a light sample reads ONE word of the row's alias table instead of searching a CDF.
 typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
 RT3_DEV uint32_t cdf_find_guided(const float* cdfp, const uint32_t* guide, uint32_t n, float u, float& lo_v, float& hi_v) {
     uint32_t k = (uint32_t)(u * (float)n);
@@ -535,8 +541,19 @@ RT3_DEV SkyPick sky_sample_direction(const SceneDev& sc, const float* cdf_marg, 
     float lo, hi;
     uint32_t y = cdf_find_guided(cdf_marg, guide_marg, H, u0, lo, hi);
     float dv = hi > lo ? (u0 - lo) / (hi - lo) : 0.5f;
-    uint32_t x = cdf_find_guided(sc.cdf_cond + (size_t)y * (W + 4), sc.guide_cond + (size_t)y * W, W, u1, lo, hi);
-    float du = hi > lo ? (u1 - lo) / (hi - lo) : 0.5f;
+    // the row's alias table (the oracle's sky_sample has the construction): cell k = floor(u1 W); xi = frac(u1 W) decides between
+    // column k and its alias and is stretched back to [0, 1) as the position inside the chosen texel.  ONE gathered word.
+    const float sx = u1 * (float)W;
+    uint32_t k = (uint32_t)sx;
+    k = k > W - 1 ? W - 1 : k;
+    float xi = sx - (float)k;
+    xi = xi < 0.99999994f ? xi : 0.99999994f;
+    const uint32_t e = sc.sky_alias[(size_t)y * W + k];
+    const float Q = (float)((e & 0xFFFFu) + 1u) * (1.0f / 65536.0f);
+    const bool keep = xi < Q;
+    const uint32_t x = keep ? k : (e >> 16);
+    float du = keep ? xi / Q : (xi - Q) / (1.0f - Q);
+    du = du < 0.99999994f ? du : 0.99999994f;
     SkyPick p;
     p.u = ((float)x + du) / (float)W;
     p.v = ((float)y + dv) / (float)H;

@@ -201,9 +201,10 @@ class Context:
         return nodes, tris
 
     def sky_download(self, w, h):
-        cc, cm, pu = np.empty((h, w), np.float32), np.empty(h, np.float32), np.empty((h, w), np.float32)
-        self.check(self.lib.rt3_sky_download(self.h, cc.ctypes.data, cm.ctypes.data, pu.ctypes.data))
-        return cc, cm, pu
+        """(alias words, RGB9E5 texels, marginal CDF, realised (u,v) density)"""
+        al, tx, cm, pu = np.empty((h, w), np.uint32), np.empty((h, w), np.uint32), np.empty(h, np.float32), np.empty((h, w), np.float32)
+        self.check(self.lib.rt3_sky_download(self.h, al.ctypes.data, tx.ctypes.data, cm.ctypes.data, pu.ctypes.data))
+        return al, tx, cm, pu
 
     def trace_rays(self, rays, any_hit=False, counts=False, repeat=1):
         """rays (8, n) float32 host SoA -> (t,u,v,prim[,n_nodes,n_tris], kernel_ms)"""

@@ -56,7 +56,7 @@ def lib():
         L.orc_scene_set_texture.argtypes = [vp, u32, vp, u32, u32]
         for n in ("orc_accel_num_tris", "orc_accel_num_nodes", "orc_accel_max_depth"):
             getattr(L, n).restype = u32; getattr(L, n).argtypes = [vp]
-        for n in ("orc_accel_nodes", "orc_accel_tris", "orc_accel_codes", "orc_sky_cdf_cond", "orc_sky_cdf_marg", "orc_sky_pdf_uv"):
+        for n in ("orc_accel_nodes", "orc_accel_tris", "orc_accel_codes", "orc_sky_alias", "orc_sky_texels", "orc_sky_cdf_marg", "orc_sky_pdf_uv"):
             getattr(L, n).restype = vp; getattr(L, n).argtypes = [vp]
         L.orc_trace_closest.argtypes = [vp, vp, u32, vp, vp, vp, vp, vp, vp, C.c_int]
         L.orc_trace_any.argtypes = [vp, vp, u32, vp, vp, vp, C.c_int]
@@ -150,10 +150,11 @@ class Scene:
 
     def sky_tables(self, w, h):
         L = lib()
-        cc = np.ctypeslib.as_array(C.cast(L.orc_sky_cdf_cond(self.h), C.POINTER(C.c_float)), (h, w)).copy()
+        al = np.ctypeslib.as_array(C.cast(L.orc_sky_alias(self.h), C.POINTER(C.c_uint32)), (h, w)).copy()
+        tx = np.ctypeslib.as_array(C.cast(L.orc_sky_texels(self.h), C.POINTER(C.c_uint32)), (h, w)).copy()
         cm = np.ctypeslib.as_array(C.cast(L.orc_sky_cdf_marg(self.h), C.POINTER(C.c_float)), (h,)).copy()
         pu = np.ctypeslib.as_array(C.cast(L.orc_sky_pdf_uv(self.h), C.POINTER(C.c_float)), (h, w)).copy()
-        return cc, cm, pu
+        return al, tx, cm, pu
 
     def trace_closest(self, rays, threads=8, counts=False):
         """rays: (8, n) float32 SoA ox,oy,oz,dx,dy,dz,tmin,tmax"""

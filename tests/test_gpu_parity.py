@@ -387,9 +387,9 @@ def test_sky_tables_match_oracle(small):
     mesh, sky, bn, osc = small
     ctx = Context(0)
     ctx.set_sky(sky)
-    cc, cm, pu = ctx.sky_download(sky.shape[1], sky.shape[0])
-    occ, ocm, opu = osc.sky_tables(sky.shape[1], sky.shape[0])
-    assert np.array_equal(cc, occ) and np.array_equal(cm, ocm) and np.array_equal(pu, opu)
+    al, tx, cm, pu = ctx.sky_download(sky.shape[1], sky.shape[0])
+    oal, otx, ocm, opu = osc.sky_tables(sky.shape[1], sky.shape[0])
+    assert np.array_equal(al, oal) and np.array_equal(tx, otx) and np.array_equal(cm, ocm) and np.array_equal(pu, opu)
     ctx.close()
 
 
