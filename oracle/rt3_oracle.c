@@ -877,9 +877,11 @@ int orc_accel_build(orc_scene *s) {
         float a[3], b[3], c[3];
         tri_positions(s, p, a, b, c);
         float *t = s->tris + 12 * (size_t)k;
+        /* the three vertices exactly as uploaded (not v0 + edges): two triangles that share an edge must see bit-identical
+         * end points, which is what makes the edge functions of tri_test watertight */
         t[0] = a[0]; t[1] = a[1]; t[2] = a[2];
-        t[3] = b[0] - a[0]; t[4] = b[1] - a[1]; t[5] = b[2] - a[2];
-        t[6] = c[0] - a[0]; t[7] = c[1] - a[1]; t[8] = c[2] - a[2];
+        t[3] = b[0]; t[4] = b[1]; t[5] = b[2];
+        t[6] = c[0]; t[7] = c[1]; t[8] = c[2];
         t[9] = u2f(p); t[10] = 0.0f; t[11] = 0.0f;
         for (int j = 0; j < 3; j++) { lmin[3 * k + j] = bmin[3 * p + j] - pad; lmax[3 * k + j] = bmax[3 * p + j] + pad; }
     }
@@ -1071,40 +1073,58 @@ uint32_t orc_accel_max_depth(const orc_scene *s) { return s->max_depth; }
 /* ------------------------------------------------------------------------------------------------ traversal */
 typedef struct { float t, u, v; uint32_t prim; } hit_t;
 
-/* [north_star] Moeller-Trumbore on precomputed (v0,e1,e2); both faces hit (no cull flags: pipeline_cache/mod.rs:326-333
- * registers a plain closest-hit group).  Acceptance: t > tmin and (t < best.t or (t == best.t and prim < best.prim)),
- * which makes the closest hit independent of traversal order. */
-/* cross / dot products of the triangle test use fused multiply-adds in a fixed order (the GPU's v_fma_f32; here
- * __builtin_fmaf, one vfmadd in the "fma" clones of the callers): x*y - z*w = fma(x, y, -(z*w)), a.b = fma(a0, b0, fma(a1, b1, a2*b2)) */
+/* [north_star] Ray / triangle test: signed-volume edge functions (Pluecker form), watertight by construction.  Both faces hit
+ * (no cull flags: pipeline_cache/mod.rs:326-333 registers a plain closest-hit group).
+ *
+ * The driver traversal the reference relies on is watertight by specification (VK_KHR_acceleration_structure).  Moeller-Trumbore
+ * in fp32 is not: a ray through a shared edge can round to u < 0 in one triangle and u + v > 1 in its neighbour (146 of 2160 rays
+ * aimed at the edge midpoints / vertices of the Cornell box slipped through; round 1 papered over it with a 2^-20 tolerance).
+ * Here, with A, B, C the vertices relative to the ray origin (each computed from its own vertex only),
+ *     U = d . (B x C)    V = d . (C x A)    W = d . (A x B)
+ * and every cross-product component is (x*y) - (z*w) with two rounded products and one subtraction (NO fused multiply-add):
+ * swapping the two vertices of an edge negates the result EXACTLY, and the dot product with d negates exactly with it.  The two
+ * triangles on either side of an edge therefore evaluate the same number for it, up to the sign their winding gives it -- whatever the
+ * rounding, a ray is on one side of the edge for both of them (on both sides when the value is exactly 0: both accept, the closest-hit
+ * rule below picks one) and cannot pass between them.  The ray is inside when U, V, W share a sign (zeros allowed), i.e. when the
+ * barycentrics w = U / det, u = V / det (vertex 1), v = W / det (vertex 2), det = U + (V + W), are all >= 0; t = sum of the vertices'
+ * distances along the ray weighted by the barycentrics, divided by d.d (no unit-length assumption on d).
+ * The test actually applied is w, u, v >= -2^-20: a SUPERSET of the sign test (so the shared-edge guarantee stands) that also closes
+ * what no watertight algorithm covers -- T-junctions and edges of separate meshes that merely coincide (the walls of the Cornell box
+ * meet the floor with different tessellations: 42 of 2160 rays aimed at those lines slipped through the exact sign test).
+ * Acceptance: t > tmin and (t < best.t or (t == best.t and prim < best.prim)), which makes the closest hit independent of traversal
+ * order.  Dot products use fused multiply-adds in a fixed order (the GPU's v_fma_f32; here __builtin_fmaf, one vfmadd in the "fma"
+ * clones of the callers): a.b = fma(a0, b0, fma(a1, b1, a2*b2)). */
 static inline float dot3f(const float a[3], const float b[3]) { return __builtin_fmaf(a[0], b[0], __builtin_fmaf(a[1], b[1], a[2] * b[2])); }
-static inline void cross3f(const float a[3], const float b[3], float o[3]) {
-    o[0] = __builtin_fmaf(a[1], b[2], -(a[2] * b[1]));
-    o[1] = __builtin_fmaf(a[2], b[0], -(a[0] * b[2]));
-    o[2] = __builtin_fmaf(a[0], b[1], -(a[1] * b[0]));
+static inline void cross3x(const float a[3], const float b[3], float o[3]) { /* exactly antisymmetric: cross3x(b, a) == -cross3x(a, b) bit for bit */
+    o[0] = (a[1] * b[2]) - (a[2] * b[1]);
+    o[1] = (a[2] * b[0]) - (a[0] * b[2]);
+    o[2] = (a[0] * b[1]) - (a[1] * b[0]);
 }
-/* fp32 Moeller-Trumbore is not watertight: a ray through a shared edge can round to u < 0 in one triangle and u + v > 1 in its
- * neighbour and slip between them (146 of 2160 rays aimed at the edge midpoints / vertices of the Cornell box did).  Triangles are
- * therefore tested slightly fat: barycentrics within 2^-20 of the edges count as hits (both neighbours then accept such a ray and the
- * closest-hit rule picks one: none of those 2160 rays leaks any more).  The driver traversal the reference uses is watertight by
- * specification; this is the cheapest restatement of that contract that keeps Moeller-Trumbore. */
 #define ORC_EDGE_EPS 9.5367431640625e-07f
-static inline void tri_test(const float *tr, const float o[3], const float d[3], float tmin, hit_t *best) {
-    const float *v0 = tr, *e1 = tr + 3, *e2 = tr + 6;
-    float pv[3], tv[3], qv[3];
-    cross3f(d, e2, pv);
-    float det = dot3f(e1, pv);
+static inline void tri_test_dd(const float *tr, const float o[3], const float d[3], float inv_dd, float tmin, hit_t *best) {
+    float A[3], B[3], C[3], bc[3], ca[3], ab[3];
+    for (int k = 0; k < 3; k++) { A[k] = tr[k] - o[k]; B[k] = tr[3 + k] - o[k]; C[k] = tr[6 + k] - o[k]; }
+    cross3x(B, C, bc); cross3x(C, A, ca); cross3x(A, B, ab);
+    const float U = dot3f(d, bc), V = dot3f(d, ca), W = dot3f(d, ab);
+    const float det = U + (V + W); /* the association of T below: equal vertex distances give t exactly */
     if (det == 0.0f) return;
-    float inv = 1.0f / det;
-    tv[0] = o[0] - v0[0]; tv[1] = o[1] - v0[1]; tv[2] = o[2] - v0[2];
-    float u = dot3f(tv, pv) * inv;
-    if (!(u >= -ORC_EDGE_EPS && u <= 1.0f + ORC_EDGE_EPS)) return;
-    cross3f(tv, e1, qv);
-    float v = dot3f(d, qv) * inv;
-    if (!(v >= -ORC_EDGE_EPS && u + v <= 1.0f + ORC_EDGE_EPS)) return;
-    float t = dot3f(e2, qv) * inv;
+    const float inv = 1.0f / det;
+    const float w = U * inv, u = V * inv, v = W * inv;
+    if (!(w >= -ORC_EDGE_EPS && u >= -ORC_EDGE_EPS && v >= -ORC_EDGE_EPS)) return;
+    const float T = __builtin_fmaf(U, dot3f(A, d), __builtin_fmaf(V, dot3f(B, d), W * dot3f(C, d)));
+    const float t = (T * inv) * inv_dd;
     uint32_t prim = f2u(tr[9]);
     if (t > tmin && (t < best->t || (t == best->t && prim < best->prim))) { best->t = t; best->u = u; best->v = v; best->prim = prim; }
 }
+static inline float ray_inv_dd(const float d[3]) { return 1.0f / dot3f(d, d); }
+/* the three edge functions of tri_test_dd for a triangle given by its vertices (tests: exact antisymmetry of a shared edge) */
+void orc_tri_edge_functions(const float *v0, const float *v1, const float *v2, const float *o, const float *d, float out[3]) {
+    float A[3], B[3], C[3], bc[3], ca[3], ab[3];
+    for (int k = 0; k < 3; k++) { A[k] = v0[k] - o[k]; B[k] = v1[k] - o[k]; C[k] = v2[k] - o[k]; }
+    cross3x(B, C, bc); cross3x(C, A, ca); cross3x(A, B, ab);
+    out[0] = dot3f(d, bc); out[1] = dot3f(d, ca); out[2] = dot3f(d, ab);
+}
+static inline void tri_test(const float *tr, const float o[3], const float d[3], float tmin, hit_t *best) { tri_test_dd(tr, o, d, ray_inv_dd(d), tmin, best); }
 static inline float guard_inv(float d) {
     float a = d < 0.0f ? -d : d;
     float g = a < 1e-20f ? (d < 0.0f ? -1e-20f : 1e-20f) : d;
@@ -1150,6 +1170,7 @@ static void traverse(const orc_scene *s, const float o[3], const float d[3], flo
     for (int k = 0; k < 3; k++) finite_ray &= (fabsf(o[k]) <= 3.4028234663852886e38f) & (fabsf(d[k]) <= 3.4028234663852886e38f);
     if (s->n_tris && finite_ray) {
         float inv[3] = {guard_inv(d[0]), guard_inv(d[1]), guard_inv(d[2])};
+        const float inv_dd = ray_inv_dd(d);
         uint32_t stack[ORC_STACK]; int sp = 0;
         uint32_t cur = 0;
         const int W4 = s->node_width == 4;
@@ -1158,7 +1179,7 @@ static void traverse(const orc_scene *s, const float o[3], const float d[3], flo
                 uint32_t first = cur & 0x0FFFFFFFu, cnt = ((cur >> 28) & 7u) + 1u, k;
                 for (k = 0; k < cnt; k++) {
                     nt++;
-                    tri_test(s->tris + 12 * (size_t)(first + k), o, d, tmin, &best);
+                    tri_test_dd(s->tris + 12 * (size_t)(first + k), o, d, inv_dd, tmin, &best);
                     if (any && best.prim != ORC_MISS) break;
                 }
                 if (any && best.prim != ORC_MISS) break;
@@ -1259,7 +1280,7 @@ void orc_trace_any(const orc_scene *s, const float *rays, uint32_t n, uint32_t *
 /* double-precision Moeller-Trumbore, used only to pin the fp32 test */
 static void tri_test_f64(const float *tr, const float of[3], const float df[3], double tmin, double *bt, double *bu, double *bv, uint32_t *bp) {
     double v0[3], e1[3], e2[3], o[3], d[3], pv[3], tv[3], qv[3];
-    for (int k = 0; k < 3; k++) { v0[k] = tr[k]; e1[k] = tr[3 + k]; e2[k] = tr[6 + k]; o[k] = of[k]; d[k] = df[k]; }
+    for (int k = 0; k < 3; k++) { v0[k] = tr[k]; e1[k] = (double)tr[3 + k] - tr[k]; e2[k] = (double)tr[6 + k] - tr[k]; o[k] = of[k]; d[k] = df[k]; }
     pv[0] = d[1] * e2[2] - d[2] * e2[1]; pv[1] = d[2] * e2[0] - d[0] * e2[2]; pv[2] = d[0] * e2[1] - d[1] * e2[0];
     double det = e1[0] * pv[0] + e1[1] * pv[1] + e1[2] * pv[2];
     if (det == 0.0) return;

@@ -121,6 +121,7 @@ const float *orc_accel_tris(const orc_scene *s);   /* n_tris  x 12 words (48 B);
 const uint64_t *orc_accel_codes(const orc_scene *s);
 uint32_t orc_accel_max_depth(const orc_scene *s);
 /* sky tables (for parity checks against the product) */
+void orc_tri_edge_functions(const float *v0, const float *v1, const float *v2, const float *o, const float *d, float out[3]);
 const uint32_t *orc_sky_alias(const orc_scene *s);  /* w*h words: q16 | alias column << 16 */
 const uint32_t *orc_sky_texels(const orc_scene *s); /* w*h RGB9E5 words */
 const float *orc_sky_cdf_marg(const orc_scene *s);

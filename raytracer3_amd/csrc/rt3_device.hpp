@@ -581,9 +581,9 @@ struct Hit {
     float t, u, v;
     uint32_t prim;
 };
-// Moeller-Trumbore on (v0, e1, e2); tri = 3 x float4: {v0.xyz,e1.x} {e1.yz,e2.xy} {e2.z,prim,-,-}.  Two-sided.
-// Order-independent acceptance: t > tmin && (t < best.t || (t == best.t && prim < best.prim)).
-// Cross / dot products use explicit fused multiply-adds in a fixed order (the oracle mirrors them with fmaf).
+// Triangle records: 3 x float4 {v0.xyz,v1.x} {v1.yz,v2.xy} {v2.z,prim,-,-}; the watertight two-sided test is tri_test_nb
+// (rt3_kernels.hip).  Order-independent acceptance: t > tmin && (t < best.t || (t == best.t && prim < best.prim)).
+// Dot products use explicit fused multiply-adds in a fixed order (the oracle mirrors them with fmaf).
 RT3_DEV float dot_fma(V3 a, V3 b) { return __builtin_fmaf(a.x, b.x, __builtin_fmaf(a.y, b.y, a.z * b.z)); }
 RT3_DEV V3 cross_fma(V3 a, V3 b) {
     return V3{__builtin_fmaf(a.y, b.z, -(a.z * b.y)), __builtin_fmaf(a.z, b.x, -(a.x * b.z)), __builtin_fmaf(a.x, b.y, -(a.y * b.x))};

@@ -41,24 +41,26 @@ __device__ __forceinline__ void cswap(Cand& a, Cand& b) {
     b.ref = sw ? ra : b.ref;
 }
 __device__ __forceinline__ void pin(float4& q) { asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w)); }
-// branch-free Moeller-Trumbore (the oracle's tri_test arithmetic and acceptance rule): no early-outs, so the three loads of a
-// triangle are issued together instead of being sunk behind the det / u / v branches
-__device__ __forceinline__ void tri_test_nb(float4 q0, float4 q1, float4 q2, V3 o, V3 d, float tmin, Hit& best) {
-    V3 v0 = v3(q0.x, q0.y, q0.z), e1 = v3(q0.w, q1.x, q1.y), e2 = v3(q1.z, q1.w, q2.x);
-    V3 pv = cross_fma(d, e2);
-    float det = dot_fma(e1, pv);
-    float inv = 1.0f / det;
-    V3 tv = o - v0;
-    float u = dot_fma(tv, pv) * inv;
-    V3 qv = cross_fma(tv, e1);
-    float v = dot_fma(d, qv) * inv;
-    float t = dot_fma(e2, qv) * inv;
-    uint32_t prim = __float_as_uint(q2.y);
-    // slightly fat triangles (barycentrics within 2^-20 of an edge count): a ray through a shared edge must not slip between the
-    // two neighbours' roundings (the oracle's tri_test has the rationale and the numbers)
+// Watertight ray / triangle test, branch-free (the oracle's tri_test_dd has the argument): edge functions as signed volumes
+// U = d.(B x C), V = d.(C x A), W = d.(A x B) of the vertices relative to the ray origin, every cross-product component two rounded
+// products and a subtraction (NO fma: the file is compiled with -ffp-contract=off), so the two triangles of a shared edge compute
+// the same number for it up to sign and no ray passes between them.  No early-outs: the three loads of a triangle are issued
+// together instead of being sunk behind branches.  Record: {v0.xyz, v1.x} {v1.yz, v2.xy} {v2.z, prim, -, -}.
+__device__ __forceinline__ V3 cross_exact(V3 a, V3 b) { return V3{(a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x)}; }
+__device__ __forceinline__ void tri_test_nb(float4 q0, float4 q1, float4 q2, V3 o, V3 d, float inv_dd, float tmin, Hit& best) {
+    const V3 A = v3(q0.x, q0.y, q0.z) - o, B = v3(q0.w, q1.x, q1.y) - o, C = v3(q1.z, q1.w, q2.x) - o;
+    const float U = dot_fma(d, cross_exact(B, C)), V = dot_fma(d, cross_exact(C, A)), W = dot_fma(d, cross_exact(A, B));
+    const float det = U + (V + W);  // the association of T below: equal vertex distances give t exactly
+    const float inv = 1.0f / det;
+    const float w = U * inv, u = V * inv, v = W * inv;
+    const float T = __builtin_fmaf(U, dot_fma(A, d), __builtin_fmaf(V, dot_fma(B, d), W * dot_fma(C, d)));
+    const float t = (T * inv) * inv_dd;
+    const uint32_t prim = __float_as_uint(q2.y);
+    // barycentrics >= -2^-20: a superset of "U, V, W share a sign" (the shared-edge guarantee stands) that also closes T-junctions
+    // and edges of separate meshes that merely coincide, which no watertight test covers
     constexpr float kEdgeEps = 9.5367431640625e-07f;
-    bool ok = (det != 0.0f) & (u >= -kEdgeEps) & (u <= 1.0f + kEdgeEps) & (v >= -kEdgeEps) & (u + v <= 1.0f + kEdgeEps) & (t > tmin) &
-              ((t < best.t) | ((t == best.t) & (prim < best.prim)));
+    const bool inside = (w >= -kEdgeEps) & (u >= -kEdgeEps) & (v >= -kEdgeEps);
+    const bool ok = (det != 0.0f) & inside & (t > tmin) & ((t < best.t) | ((t == best.t) & (prim < best.prim)));
     best.t = ok ? t : best.t;
     best.u = ok ? u : best.u;
     best.v = ok ? v : best.v;
@@ -86,7 +88,7 @@ void set_trace_blocks(uint32_t v) { g_trace_max_blocks = v; }
 
 struct LaneRay {  // traversal state of the ray a lane currently owns
     V3 o, d, inv;
-    float tmin;
+    float tmin, inv_dd;  // inv_dd = 1 / d.d (the triangle test makes no unit-length assumption)
     Hit best;
     uint32_t cur, leaf_k, index, steps, cn, ct;
     int sp;
@@ -129,6 +131,7 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
     LaneRay r;
     r.o = r.d = r.inv = v3(0.0f, 0.0f, 0.0f);
     r.tmin = 0.0f;
+    r.inv_dd = 1.0f;
     r.best = Hit{0.0f, 0.0f, 0.0f, kMiss};
     r.cur = r.leaf_k = r.index = r.steps = r.cn = r.ct = 0u;
     r.sp = 0;
@@ -174,6 +177,7 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
                 r.pay0 = ro.w;
                 r.pay1 = rd.w;
                 r.inv = v3(guarded_inverse(r.d.x), guarded_inverse(r.d.y), guarded_inverse(r.d.z));
+                r.inv_dd = 1.0f / dot_fma(r.d, r.d);
                 r.cur = 0u;
                 r.leaf_k = 0u;
                 r.sp = 0;
@@ -223,12 +227,12 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
         const float tmin = r.tmin;
         if (is_leaf) {
             if (COUNT) r.ct++;
-            tri_test_nb(q0, q1, q2, o, d, tmin, r.best);
+            tri_test_nb(q0, q1, q2, o, d, r.inv_dd, tmin, r.best);
             r.leaf_k++;
             if (WIDE) {  // the 128 B fetch holds a second triangle
                 if (r.leaf_k < cnt && !(ANY && r.best.prim != kMiss)) {
                     if (COUNT) r.ct++;
-                    tri_test_nb(q3, q4, q5, o, d, tmin, r.best);
+                    tri_test_nb(q3, q4, q5, o, d, r.inv_dd, tmin, r.best);
                     r.leaf_k++;
                 }
             }

@@ -4,7 +4,7 @@
 //   k_prim_bounds  triangle boxes + scene / centroid bounds (wave reduce, ordered-uint atomics)
 //   k_morton       63-bit Morton code of the box centre (21 bits per axis)
 //   hipcub radix sort of (code, primitive) pairs, 64-bit keys, stable -> ties keep primitive order
-//   k_leaves       Morton-ordered triangle records {v0,e1,e2,prim} (48 B) + padded leaf boxes
+//   k_leaves       Morton-ordered triangle records {v0,v1,v2,prim} (48 B) + padded leaf boxes
 //   k_hierarchy    Karras 2012 radix-tree topology, one thread per internal node
 //   k_refit        bottom-up boxes of every binary node: the second thread to arrive at a node (agent-scope atomic +
 //                  fences) merges the two child boxes and climbs on
@@ -148,10 +148,11 @@ __global__ void k_leaves(const float* verts, const uint32_t* indices, const Geom
         uint32_t p = sorted_prim[k];
         V3 a, b, c;
         fetch_triangle(verts, indices, geoms, prim_geom, first_prim, p, a, b, c);
-        V3 e1 = b - a, e2 = c - a;
-        tris[3 * (size_t)k + 0] = make_float4(a.x, a.y, a.z, e1.x);
-        tris[3 * (size_t)k + 1] = make_float4(e1.y, e1.z, e2.x, e2.y);
-        tris[3 * (size_t)k + 2] = make_float4(e2.z, __uint_as_float(p), 0.0f, 0.0f);
+        // the three vertices exactly as uploaded (not v0 + edges): triangles that share an edge must see bit-identical end points
+        // for the watertight edge functions of the triangle test
+        tris[3 * (size_t)k + 0] = make_float4(a.x, a.y, a.z, b.x);
+        tris[3 * (size_t)k + 1] = make_float4(b.y, b.z, c.x, c.y);
+        tris[3 * (size_t)k + 2] = make_float4(c.z, __uint_as_float(p), 0.0f, 0.0f);
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             lmin[3 * (size_t)k + j] = bmin[3 * (size_t)p + j] - pad;

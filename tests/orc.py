@@ -253,3 +253,42 @@ def tile_pixels(w, h, rank, n_ranks):
     out = np.empty((n, 2), np.uint32)
     lib().orc_tile_pixels(w, h, rank, n_ranks, ptr(out))
     return out
+
+
+def shared_edge_rays(mesh, h=0.02, seed=0, limit=None):
+    """Watertightness sweep: for every edge that two triangles share (bit-identical end points) and every vertex whose edges are all
+    shared, rays from both sides of the surface (offset `h` along the triangle's geometric normal) aimed exactly at the edge midpoint /
+    the vertex.  Returns (rays (8, m) float32, h): a ray that does not hit within h + 1e-3 has slipped between the two triangles."""
+    tri = mesh.triangle_positions().astype(np.float32)
+    n = np.cross((tri[:, 1] - tri[:, 0]).astype(np.float64), (tri[:, 2] - tri[:, 0]).astype(np.float64))
+    ln = np.linalg.norm(n, axis=1)
+    ok = ln > 1e-12
+    tri, n = tri[ok], (n[ok] / ln[ok, None])
+    keys = tri.view(np.uint32).reshape(len(tri), 3, 3)
+    _, vid = np.unique(keys.reshape(-1, 3), axis=0, return_inverse=True)  # vertex identity = its exact position
+    vid = vid.reshape(-1, 3)
+    e = np.stack([vid[:, [0, 1]], vid[:, [1, 2]], vid[:, [2, 0]]], 1)  # (t, 3, 2)
+    ek = np.sort(e.reshape(-1, 2), axis=1)
+    ekey = ek[:, 0].astype(np.int64) * (vid.max() + 1) + ek[:, 1]
+    uniq, inv, cnt = np.unique(ekey, return_inverse=True, return_counts=True)
+    shared = (cnt[inv] == 2).reshape(-1, 3)  # per triangle edge
+    mids = np.stack([(tri[:, 0].astype(np.float64) + tri[:, 1]) / 2, (tri[:, 1].astype(np.float64) + tri[:, 2]) / 2, (tri[:, 2].astype(np.float64) + tri[:, 0]) / 2], 1)
+    targets = [mids[shared], ]
+    normals = [np.repeat(n[:, None, :], 3, 1)[shared], ]
+    # vertices all of whose incident edges are shared
+    bad_v = np.zeros(vid.max() + 1, bool)
+    np.logical_or.at(bad_v, e[~shared].reshape(-1), True)
+    vgood = ~bad_v[vid]
+    targets.append(tri.astype(np.float64)[vgood])
+    normals.append(np.repeat(n[:, None, :], 3, 1)[vgood])
+    T, N = np.concatenate(targets), np.concatenate(normals)
+    if limit and len(T) > limit:
+        pick = np.random.default_rng(seed).choice(len(T), limit, replace=False)
+        T, N = T[pick], N[pick]
+    rays = []
+    for sgn in (1.0, -1.0):
+        o = (T + sgn * h * N).astype(np.float32)
+        d = T.astype(np.float32) - o
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        rays.append(np.concatenate([o.T, d.T, np.full((1, len(o)), 1e-4, np.float32), np.full((1, len(o)), 1e5, np.float32)]))
+    return np.ascontiguousarray(np.concatenate(rays, 1), np.float32), h
