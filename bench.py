@@ -297,11 +297,16 @@ def main():
     # tools/summarize_profile.py into profiles/*_traffic.json.  Quoted only for the default workload they were collected on AND
     # only while the kernel's average duration in that profile agrees with this run's within 5 % (a stale profile is not evidence).
     prof = None
-    tfiles = sorted((ROOT / "profiles").glob("r*_traffic.json"))
-    if tfiles and default_workload and world == 1:
-        tj = json.loads(tfiles[-1].read_text())
-        tj["_file"] = f"profiles/{tfiles[-1].name}"
-        prof = tj
+    if default_workload and world == 1:  # of the committed profiles, the one whose dominant-kernel time is closest to this run's
+        best_gap = None
+        for tf in sorted((ROOT / "profiles").glob("r*_traffic.json")):
+            tj = json.loads(tf.read_text())
+            kk = [v for k, v in tj["kernels"].items() if k.startswith(f"rt3::{dom_name}<false") and v.get("avg_ms")]
+            if not kk or avg_ms <= 0:
+                continue
+            gap = abs(kk[0]["avg_ms"] / avg_ms - 1.0)
+            if best_gap is None or gap < best_gap:
+                best_gap, prof = gap, dict(tj, _file=f"profiles/{tf.name}")
 
     def prof_kernel(prefix):
         if prof is None:

@@ -128,9 +128,10 @@ int rt3_device_name(rt3_ctx *ctx, char *buf, size_t buf_size);
 #define RT3_OPT_WIDE_COLLAPSE 8   /* width 4 only: how binary LBVH nodes are grouped into four-wide nodes: 1 = by surface area (default), 0 = even binary depth */
 #define RT3_OPT_POOL_CHUNK 9      /* traversal tuning: rays a wave takes from the launch's ray pool per grab (default 256) */
 #define RT3_OPT_FUSED_TRACE 10    /* 1: one k_trace launch per bounce walks the extension queue and then the shadow queue; 0 (default): separate k_shadow and k_extend launches */
-#define RT3_OPT_SAH_TOP 11       /* T > 0 (default 2): the tree above Karras subtrees of at most T triangles is re-linked by binned SAH on the
-                                     host (the reference asks its driver for PREFER_FAST_TRACE builds, raytracing.rs:103,131); 0 = plain GPU LBVH */
+#define RT3_OPT_SAH_TOP 11       /* T > 0 (default 2): the tree above Karras subtrees of at most T triangles is re-linked by binned SAH
+                                     (the reference asks its driver for PREFER_FAST_TRACE builds, raytracing.rs:103,131); 0 = plain LBVH */
 #define RT3_OPT_TRACE_BLOCKS 12   /* traversal tuning: persistent workgroups (256 threads) per traversal launch (default 2048 = 8 per CU) */
+#define RT3_OPT_SAH_TOP_DEVICE 13  /* 1 (default): the SAH top is built on the GPU, no bulk copies; 0: on the host (same tree, bit for bit) */
 int rt3_set_option(rt3_ctx *ctx, int option, int64_t value);
 
 /* ---- scene upload: DynamicBuffer::push (vulkan/buffer.rs:406-420) into the world buffers of

@@ -18,7 +18,7 @@ BACKGROUND_DEPTH = 100000.0
 FORMAT_R32_SFLOAT, FORMAT_R32G32B32A32_SFLOAT, FORMAT_R32G32B32A32_UINT, FORMAT_R8G8B8A8_UNORM, FORMAT_R16_UINT = 100, 109, 107, 37, 74
 F_NEE_SKY, F_BLUENOISE, F_SPECULAR, F_FACEFORWARD, F_PROBE_RADIANCE = 1, 2, 4, 8, 16
 OPT_BATCH_SPP, OPT_PROFILE, OPT_COUNT_TRAVERSAL, OPT_EXTEND_VARIANT, OPT_LEAF_SIZE, OPT_NODE_WIDTH, OPT_NODE_QUANT = 1, 2, 3, 4, 5, 6, 7
-OPT_WIDE_COLLAPSE, OPT_POOL_CHUNK, OPT_FUSED_TRACE, OPT_SAH_TOP, OPT_TRACE_BLOCKS = 8, 9, 10, 11, 12
+OPT_WIDE_COLLAPSE, OPT_POOL_CHUNK, OPT_FUSED_TRACE, OPT_SAH_TOP, OPT_TRACE_BLOCKS, OPT_SAH_TOP_DEVICE = 8, 9, 10, 11, 12, 13
 
 EXPORTS = [
     "rt3_create", "rt3_destroy", "rt3_last_error", "rt3_device_name", "rt3_set_option",

@@ -115,7 +115,7 @@ struct rt3_ctx {
     int64_t opt_batch_spp = 0;
     bool opt_profile = false, opt_count = false;
     int opt_variant = 0;  // RT3_OPT_EXTEND_VARIANT: reserved for traversal experiments
-    uint32_t opt_leaf_size = 2, opt_node_width = 4, opt_node_quant = 1, opt_collapse = 1, opt_sah_top = 2;
+    uint32_t opt_leaf_size = 2, opt_node_width = 4, opt_node_quant = 1, opt_collapse = 1, opt_sah_top = 2, opt_sah_device = 1;
     int opt_fused_trace = 0;  // 1: k_trace (extension + shadow queue in one launch per bounce)
     rt3_stats stats;
     uint64_t primary_rays_pending = 0;
@@ -727,6 +727,7 @@ int rt3_set_option(rt3_ctx* c, int option, int64_t value) {
         case RT3_OPT_COUNT_TRAVERSAL: c->opt_count = value != 0; return RT3_OK;
         case RT3_OPT_EXTEND_VARIANT:
             c->opt_variant = (int)value;
+            HIPC(c, hipSetDevice(c->device));  // the traversal knobs are __constant__ words of the device the context runs on
             set_refill_lanes((uint32_t)value);
             return RT3_OK;
         case RT3_OPT_LEAF_SIZE:
@@ -744,12 +745,18 @@ int rt3_set_option(rt3_ctx* c, int option, int64_t value) {
             c->opt_sah_top = (uint32_t)value;
             c->accel_built = false;
             return RT3_OK;
+        case RT3_OPT_SAH_TOP_DEVICE:
+            if (value != 0 && value != 1) return fail(c, RT3_E_INVALID, "SAH-top device must be 0 (host) or 1 (GPU)");
+            c->opt_sah_device = (uint32_t)value;
+            c->accel_built = false;
+            return RT3_OK;
         case RT3_OPT_FUSED_TRACE:
             if (value < 0 || value > 1) return fail(c, RT3_E_INVALID, "fused trace must be 0 or 1");
             c->opt_fused_trace = (int)value;
             return RT3_OK;
         case RT3_OPT_POOL_CHUNK:
             if (value < 64 || value > 65536 || (value & 63)) return fail(c, RT3_E_INVALID, "pool chunk must be a multiple of 64 in [64, 65536]");
+            HIPC(c, hipSetDevice(c->device));
             set_pool_chunk((uint32_t)value);
             return RT3_OK;
         case RT3_OPT_TRACE_BLOCKS:
@@ -1033,7 +1040,7 @@ int rt3_accel_build(rt3_ctx* c, uint32_t* out_handle) {
     dev_free(c->bvh.tris);
     dev_free(c->bvh.tri_shade);
     hipError_t e = lbvh_build(c->stream, c->d_verts, c->d_indices, c->d_geoms, c->d_prim_geom, c->d_first_prim, c->n_prims, c->opt_leaf_size,
-                              c->opt_node_width, c->opt_node_quant, c->opt_collapse, c->opt_sah_top, &c->bvh);
+                              c->opt_node_width, c->opt_node_quant, c->opt_collapse, c->opt_sah_top, c->opt_sah_device, &c->bvh);
     if (e != hipSuccess) return fail(c, RT3_E_HIP, std::string("lbvh_build: ") + hipGetErrorString(e));
     // worst-case stack use of the near-first walk: (children per node - 1) entries per level above the leaves
     const uint32_t stack_need = c->bvh.max_depth > 1 ? (c->opt_node_width - 1) * (c->bvh.max_depth - 1) : 0;

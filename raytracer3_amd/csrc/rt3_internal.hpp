@@ -100,6 +100,6 @@ struct LbvhResult {
 };
 hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,
                       const uint32_t* first_prim, uint32_t n_prims, uint32_t leaf_max, uint32_t node_width, uint32_t node_quant, uint32_t collapse_mode,
-                      uint32_t sah_top, LbvhResult* out);
+                      uint32_t sah_top, uint32_t sah_device, LbvhResult* out);
 
 }  // namespace rt3

@@ -731,6 +731,549 @@ bool sah_top_relink(uint32_t nn, uint32_t* left, uint32_t* right, uint32_t* rcnt
 }
 }  // namespace
 
+// ---- SAH top on the GPU (RT3_OPT_SAH_TOP_DEVICE, default): the same algorithm as sah_top_relink above, same fp32 expressions in the
+// same order, so the tree is bit-identical to the host's and the oracle's -- every reduction in it is a min, a max or an integer
+// sum (exact, order independent), and the partitions are stable.  No bulk D2H / H2D copies: the Karras arrays are re-linked in place.
+//   k_sah_mark / scans / k_sah_gather   top nodes -> pool[] (ascending), their cluster children -> cl_*[] (node order, left first)
+//   k_sah_block  one workgroup per segment of more than kSahSmall clusters, one launch per level: centroid bounds and 3 x 16 bins by
+//                LDS atomics on order-preserving uints, the split sweep by thread 0, a stable in-place partition in 256-wide chunks
+//   k_sah_small  one thread per remaining segment (<= kSahSmall clusters) running the sequential algorithm with its own stack
+// A subtree over n clusters owns n - 1 pool nodes in pre-order (as on the host), so segments touch disjoint ranges.
+namespace {
+constexpr uint32_t kSahSmall = 16;    // segments of at most this many clusters are finished by one thread
+constexpr uint32_t kSahHuge = 4096;   // segments of more clusters get a 1024-thread workgroup, the others 256 threads
+struct SahSeg { uint32_t a, n, pool, patch; };
+struct SahArrays {
+    uint32_t *left, *right, *rcnt, *pint, *pleaf;   // the Karras tree, re-linked in place
+    const uint32_t *cl_ref, *cl_cnt;                // clusters
+    const float *cl_mn, *cl_mx;                     // 3 floats each
+    const uint32_t* pool;
+    uint32_t *idx, *tmp;
+    uint32_t T;
+};
+__device__ __forceinline__ float sah_half_area(const float* mn, const float* mx) {
+    const float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
+    return (ex * ey + ey * ez) + ez * ex;
+}
+__device__ __forceinline__ void sah_patch_parent(const SahArrays& A, uint32_t patch, uint32_t ref) {
+    if (patch == 0xFFFFFFFFu) return;
+    const uint32_t parent = patch >> 1;
+    if (patch & 1u) A.right[parent] = ref;
+    else A.left[parent] = ref;
+    if (ref & 0x80000000u) A.pleaf[ref & 0x7FFFFFFFu] = parent;
+    else A.pint[ref] = parent;
+}
+// the sweep over the 15 split planes of one axis (sah_top_relink::split, inner part); bins hold decoded floats
+__device__ __forceinline__ void sah_sweep_axis(int axis, const float (*bmn)[3], const float (*bmx)[3], const uint32_t* bc, float& best_cost, int& best_axis,
+                                               int& best_split) {
+    const float inf = INFINITY;
+    float rmn[16][3], rmx[16][3];
+    uint32_t rc[16];
+    for (int b = 15; b >= 0; b--) {
+        for (int q = 0; q < 3; q++) {
+            rmn[b][q] = b == 15 ? bmn[b][q] : fmin_sel(bmn[b][q], rmn[b + 1][q]);
+            rmx[b][q] = b == 15 ? bmx[b][q] : fmax_sel(bmx[b][q], rmx[b + 1][q]);
+        }
+        rc[b] = bc[b] + (b == 15 ? 0u : rc[b + 1]);
+    }
+    float lmn[3] = {inf, inf, inf}, lmx[3] = {-inf, -inf, -inf};
+    uint32_t lc = 0;
+    for (int sp = 1; sp < 16; sp++) {
+        for (int q = 0; q < 3; q++) {
+            lmn[q] = fmin_sel(lmn[q], bmn[sp - 1][q]);
+            lmx[q] = fmax_sel(lmx[q], bmx[sp - 1][q]);
+        }
+        lc += bc[sp - 1];
+        if (lc == 0 || rc[sp] == 0) continue;
+        const float cost = sah_half_area(lmn, lmx) * (float)lc + sah_half_area(rmn[sp], rmx[sp]) * (float)rc[sp];
+        if (cost < best_cost) {
+            best_cost = cost;
+            best_axis = axis;
+            best_split = sp;
+        }
+    }
+}
+__device__ __forceinline__ int sah_bin(float ce, float cmn, float ext) {
+    int b = (int)(((ce - cmn) / ext) * 16.0f);
+    return b > 15 ? 15 : b;
+}
+
+__global__ void k_sah_mark(const uint32_t* left, const uint32_t* right, const uint32_t* rcnt, uint32_t nn, uint32_t T, uint32_t* top, uint32_t* ncl) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += gridDim.x * blockDim.x) {
+        const bool t = i == 0 || rcnt[i] > T;
+        uint32_t c = 0;
+        if (t) {
+            const uint32_t c2[2] = {left[i], right[i]};
+            for (int k = 0; k < 2; k++)
+                if ((c2[k] & 0x80000000u) || rcnt[c2[k]] <= T) c++;
+        }
+        top[i] = t ? 1u : 0u;
+        ncl[i] = c;
+    }
+}
+__global__ void k_sah_gather(const uint32_t* left, const uint32_t* right, const uint32_t* rcnt, uint32_t nn, uint32_t T, const uint32_t* top, const uint32_t* pool_pos,
+                             const uint32_t* cl_pos, const float* lmin, const float* lmax, const float* nbox, uint32_t* pool, uint32_t* cl_ref, uint32_t* cl_cnt,
+                             float* cl_mn, float* cl_mx, uint32_t* idx) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += gridDim.x * blockDim.x) {
+        if (!top[i]) continue;
+        pool[pool_pos[i]] = i;
+        uint32_t k = cl_pos[i];
+        const uint32_t c2[2] = {left[i], right[i]};
+        for (int c = 0; c < 2; c++) {
+            const uint32_t ch = c2[c];
+            if (!(ch & 0x80000000u) && rcnt[ch] > T) continue;  // another top node
+            cl_ref[k] = ch;
+            if (ch & 0x80000000u) {
+                const uint32_t q = ch & 0x7FFFFFFFu;
+                cl_cnt[k] = 1;
+                for (int a = 0; a < 3; a++) {
+                    cl_mn[3 * (size_t)k + a] = lmin[3 * (size_t)q + a];
+                    cl_mx[3 * (size_t)k + a] = lmax[3 * (size_t)q + a];
+                }
+            } else {
+                cl_cnt[k] = rcnt[ch];
+                for (int a = 0; a < 3; a++) {
+                    cl_mn[3 * (size_t)k + a] = nbox[6 * (size_t)ch + a];
+                    cl_mx[3 * (size_t)k + a] = nbox[6 * (size_t)ch + 3 + a];
+                }
+            }
+            idx[k] = k;
+            k++;
+        }
+    }
+}
+
+// children of a split segment: single clusters are linked at once, the others queued by size (huge / big -> next level, small -> k_sah_small)
+struct SahQueues {
+    SahSeg *huge, *big, *small;
+    uint32_t* counts;   // [0] huge, [1] big segments of the next level
+    uint32_t* n_small;
+};
+__device__ __forceinline__ void sah_emit_child(const SahArrays& A, SahSeg c, const SahQueues& Q) {
+    if (c.n == 1) sah_patch_parent(A, c.patch, A.cl_ref[A.idx[c.a]]);
+    else if (c.n > kSahHuge) Q.huge[atomicAdd(&Q.counts[0], 1u)] = c;
+    else if (c.n > kSahSmall) Q.big[atomicAdd(&Q.counts[1], 1u)] = c;
+    else Q.small[atomicAdd(Q.n_small, 1u)] = c;
+}
+__device__ __forceinline__ float wave_min_f(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmin_sel(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmax_sel(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum_u(uint32_t v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// One workgroup per segment.  Contention-free by construction: centroid bounds are reduced in registers and then across the wave;
+// bins are reduced across the lanes of a wave that share a bin (clusters are in Morton sub-order, a wave's 64 consecutive ones
+// fall into one to three bins) and only the wave's leader lane touches the LDS counters.  min / max / integer sums: exact in any order.
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_sah_block(SahArrays A, const SahSeg* segs, const uint32_t* n_segs, SahQueues Q) {
+    __shared__ uint32_t s_cmn[3], s_cmx[3], s_total;
+    __shared__ uint32_t s_bmn[3][16][3], s_bmx[3][16][3], s_bc[3][16];
+    __shared__ int s_axis, s_split;
+    __shared__ float s_cost[3][16];
+    __shared__ uint32_t s_w, s_r, s_wave[BLOCK / 64][2];
+    if (blockIdx.x >= *n_segs) return;  // the grid is sized for the most segments a level can have: no host round trip per level
+    const SahSeg j = segs[blockIdx.x];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t node = A.pool[j.pool];
+    const float inf = INFINITY;
+    if (tid < 3) {
+        s_cmn[tid] = float_to_ordered(inf);
+        s_cmx[tid] = float_to_ordered(-inf);
+    }
+    if (tid == 0) s_total = 0;
+    for (uint32_t k = tid; k < 3 * 16 * 3; k += BLOCK) {
+        (&s_bmn[0][0][0])[k] = float_to_ordered(inf);
+        (&s_bmx[0][0][0])[k] = float_to_ordered(-inf);
+    }
+    for (uint32_t k = tid; k < 3 * 16; k += BLOCK) (&s_bc[0][0])[k] = 0;
+    __syncthreads();
+    {  // centroid bounds, triangle total
+        float tmn[3] = {inf, inf, inf}, tmx[3] = {-inf, -inf, -inf};
+        uint32_t tc = 0;
+        for (uint32_t k0 = tid; k0 < j.n; k0 += 4 * BLOCK) {  // four independent elements per trip: this loop lives off loads in flight
+            uint32_t c[4], cc[4];
+            float mn[4][3], mx[4][3];
+#pragma unroll
+            for (int e = 0; e < 4; e++) c[e] = k0 + e * BLOCK < j.n ? A.idx[j.a + k0 + e * BLOCK] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const bool ok = c[e] != 0xFFFFFFFFu;
+                cc[e] = ok ? A.cl_cnt[c[e]] : 0u;
+                for (int a = 0; a < 3; a++) {
+                    mn[e][a] = ok ? A.cl_mn[3 * (size_t)c[e] + a] : 0.0f;
+                    mx[e][a] = ok ? A.cl_mx[3 * (size_t)c[e] + a] : 0.0f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                if (c[e] == 0xFFFFFFFFu) continue;
+                tc += cc[e];
+                for (int a = 0; a < 3; a++) {
+                    const float ce = (mn[e][a] + mx[e][a]) * 0.5f;
+                    tmn[a] = fmin_sel(tmn[a], ce);
+                    tmx[a] = fmax_sel(tmx[a], ce);
+                }
+            }
+        }
+        tc = wave_sum_u(tc);
+        for (int a = 0; a < 3; a++) {
+            tmn[a] = wave_min_f(tmn[a]);
+            tmx[a] = wave_max_f(tmx[a]);
+        }
+        if (lane == 0) {
+            atomicAdd(&s_total, tc);
+            for (int a = 0; a < 3; a++) {
+                atomicMin(&s_cmn[a], float_to_ordered(tmn[a]));
+                atomicMax(&s_cmx[a], float_to_ordered(tmx[a]));
+            }
+        }
+    }
+    __syncthreads();
+    float cmn[3], ext[3];
+    for (int a = 0; a < 3; a++) {
+        cmn[a] = ordered_to_float(s_cmn[a]);
+        ext[a] = ordered_to_float(s_cmx[a]) - cmn[a];
+    }
+    const uint32_t n_round = (j.n + 63u) & ~63u;  // whole waves iterate: cross-lane reductions inside
+    for (uint32_t k0 = tid; k0 < n_round; k0 += 4 * BLOCK) {  // 3 x 16 bins; the loads of four elements are issued together
+        uint32_t ce4[4], cnt4[4];
+        float mn4[4][3], mx4[4][3];
+#pragma unroll
+        for (int e = 0; e < 4; e++) ce4[e] = k0 + e * BLOCK < j.n ? A.idx[j.a + k0 + e * BLOCK] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const bool ok = ce4[e] != 0xFFFFFFFFu;
+            cnt4[e] = ok ? A.cl_cnt[ce4[e]] : 0u;
+            for (int q = 0; q < 3; q++) {
+                mn4[e][q] = ok ? A.cl_mn[3 * (size_t)ce4[e] + q] : inf;
+                mx4[e][q] = ok ? A.cl_mx[3 * (size_t)ce4[e] + q] : -inf;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            if (k0 - tid + e * BLOCK >= n_round) break;  // (uniform over the wave: n_round and the wave's base are multiples of 64)
+            const bool valid = ce4[e] != 0xFFFFFFFFu;
+            const uint32_t cnt = cnt4[e];
+            const float* mn = mn4[e];
+            const float* mx = mx4[e];
+            for (int a = 0; a < 3; a++) {
+                if (!(ext[a] > 0.0f)) continue;  // (uniform over the workgroup)
+                const int b = valid ? sah_bin((mn[a] + mx[a]) * 0.5f, cmn[a], ext[a]) : -1;
+                unsigned long long todo = __ballot(valid);
+                while (todo) {  // one round per distinct bin among the wave's lanes
+                    const int leader = __ffsll((long long)todo) - 1;
+                    const int bb = __shfl(b, leader);
+                    const bool mine = b == bb;
+                    const unsigned long long peers = __ballot(mine);
+                    const uint32_t sc = wave_sum_u(mine ? cnt : 0u);
+                    float rmn[3], rmx[3];
+                    for (int q = 0; q < 3; q++) {
+                        rmn[q] = wave_min_f(mine ? mn[q] : inf);
+                        rmx[q] = wave_max_f(mine ? mx[q] : -inf);
+                    }
+                    if ((int)lane == leader) {
+                        atomicAdd(&s_bc[a][bb], sc);
+                        for (int q = 0; q < 3; q++) {
+                            atomicMin(&s_bmn[a][bb][q], float_to_ordered(rmn[q]));
+                            atomicMax(&s_bmx[a][bb][q], float_to_ordered(rmx[q]));
+                        }
+                    }
+                    todo &= ~peers;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 48) {  // the 3 x 15 split planes in parallel: the same left / right boxes, counts and cost expression as the sequential sweep
+        const int a = (int)tid >> 4, sp = (int)tid & 15;
+        float cost = inf;
+        if (sp >= 1 && ext[a] > 0.0f) {
+            float lmn[3] = {inf, inf, inf}, lmx[3] = {-inf, -inf, -inf}, rmn[3] = {inf, inf, inf}, rmx[3] = {-inf, -inf, -inf};
+            uint32_t lc = 0, rc = 0;
+            for (int b = 0; b < sp; b++) {
+                lc += s_bc[a][b];
+                for (int q = 0; q < 3; q++) {
+                    lmn[q] = fmin_sel(lmn[q], ordered_to_float(s_bmn[a][b][q]));
+                    lmx[q] = fmax_sel(lmx[q], ordered_to_float(s_bmx[a][b][q]));
+                }
+            }
+            for (int b = 15; b >= sp; b--) {
+                rc += s_bc[a][b];
+                for (int q = 0; q < 3; q++) {
+                    rmn[q] = fmin_sel(rmn[q], ordered_to_float(s_bmn[a][b][q]));
+                    rmx[q] = fmax_sel(rmx[q], ordered_to_float(s_bmx[a][b][q]));
+                }
+            }
+            if (lc != 0 && rc != 0) cost = sah_half_area(lmn, lmx) * (float)lc + sah_half_area(rmn, rmx) * (float)rc;
+        }
+        s_cost[a][sp] = cost;
+    }
+    __syncthreads();
+    if (tid == 0) {  // first minimum in (axis, plane) order, like the sequential sweep's strict `<`
+        float best_cost = inf;
+        int best_axis = -1, best_split = 0;
+        for (int a = 0; a < 3; a++)
+            for (int sp = 1; sp < 16; sp++)
+                if (s_cost[a][sp] < best_cost) {
+                    best_cost = s_cost[a][sp];
+                    best_axis = a;
+                    best_split = sp;
+                }
+        s_axis = best_axis;
+        s_split = best_split;
+        s_w = 0;
+        s_r = 0;
+    }
+    __syncthreads();
+    const int axis = s_axis, split = s_split;
+    uint32_t nl;
+    if (axis < 0) {
+        nl = j.n / 2;  // coincident centroids: halve in index order
+    } else {
+        // stable partition, in place, BLOCK elements at a time: lefts go to idx[a + w ..] (w never passes the chunk being read),
+        // rights to tmp[a + r ..] and are appended behind the lefts at the end
+        for (uint32_t base = 0; base < j.n; base += BLOCK) {
+            const uint32_t k = base + tid;
+            const bool valid = k < j.n;
+            uint32_t c = 0;
+            bool goes_left = false;
+            if (valid) {
+                c = A.idx[j.a + k];
+                const float ce = (A.cl_mn[3 * (size_t)c + axis] + A.cl_mx[3 * (size_t)c + axis]) * 0.5f;
+                goes_left = sah_bin(ce, cmn[axis], ext[axis]) < split;
+            }
+            const unsigned long long ml = __ballot(valid && goes_left), mr = __ballot(valid && !goes_left);
+            if (lane == 0) {
+                s_wave[wave][0] = (uint32_t)__popcll(ml);
+                s_wave[wave][1] = (uint32_t)__popcll(mr);
+            }
+            __syncthreads();  // every thread has read its element of this chunk
+            uint32_t wl = s_w, wr = s_r;
+            for (uint32_t q = 0; q < wave; q++) {
+                wl += s_wave[q][0];
+                wr += s_wave[q][1];
+            }
+            const unsigned long long below = (1ull << lane) - 1ull;
+            if (valid) {
+                if (goes_left) A.idx[j.a + wl + (uint32_t)__popcll(ml & below)] = c;
+                else A.tmp[j.a + wr + (uint32_t)__popcll(mr & below)] = c;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t tl = 0, tr = 0;
+                for (int q = 0; q < BLOCK / 64; q++) {
+                    tl += s_wave[q][0];
+                    tr += s_wave[q][1];
+                }
+                s_w += tl;
+                s_r += tr;
+            }
+            __syncthreads();
+        }
+        nl = s_w;
+        const uint32_t nr = s_r;
+        for (uint32_t k = tid; k < nr; k += BLOCK) A.idx[j.a + nl + k] = A.tmp[j.a + k];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const uint32_t total = s_total;
+        A.rcnt[node] = total > A.T ? total : A.T + 1u;
+        sah_patch_parent(A, j.patch, node);
+        sah_emit_child(A, SahSeg{j.a, nl, j.pool + 1, node << 1}, Q);
+        sah_emit_child(A, SahSeg{j.a + nl, j.n - nl, j.pool + nl, (node << 1) | 1u}, Q);
+    }
+}
+
+// one thread per segment of at most kSahSmall clusters: sah_top_relink's loop, with a private stack
+__global__ void k_sah_small(SahArrays A, const SahSeg* segs, uint32_t n_segs) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_segs) return;
+    SahSeg st[kSahSmall + 2];
+    int sp = 0;
+    st[sp++] = segs[s];
+    const float inf = INFINITY;
+    while (sp > 0) {
+        const SahSeg j = st[--sp];
+        if (j.n == 1) {
+            sah_patch_parent(A, j.patch, A.cl_ref[A.idx[j.a]]);
+            continue;
+        }
+        const uint32_t node = A.pool[j.pool];
+        float cmn[3] = {inf, inf, inf}, cmx[3] = {-inf, -inf, -inf};
+        uint32_t total = 0;
+        for (uint32_t k = 0; k < j.n; k++) {
+            const uint32_t c = A.idx[j.a + k];
+            total += A.cl_cnt[c];
+            for (int a = 0; a < 3; a++) {
+                const float ce = (A.cl_mn[3 * (size_t)c + a] + A.cl_mx[3 * (size_t)c + a]) * 0.5f;
+                cmn[a] = fmin_sel(cmn[a], ce);
+                cmx[a] = fmax_sel(cmx[a], ce);
+            }
+        }
+        float best_cost = inf;
+        int best_axis = -1, best_split = 0;
+        for (int a = 0; a < 3; a++) {
+            const float ext = cmx[a] - cmn[a];
+            if (!(ext > 0.0f)) continue;
+            float bmn[16][3], bmx[16][3];
+            uint32_t bc[16];
+            for (int b = 0; b < 16; b++) {
+                bc[b] = 0;
+                for (int q = 0; q < 3; q++) {
+                    bmn[b][q] = inf;
+                    bmx[b][q] = -inf;
+                }
+            }
+            for (uint32_t k = 0; k < j.n; k++) {
+                const uint32_t c = A.idx[j.a + k];
+                const int b = sah_bin((A.cl_mn[3 * (size_t)c + a] + A.cl_mx[3 * (size_t)c + a]) * 0.5f, cmn[a], ext);
+                bc[b] += A.cl_cnt[c];
+                for (int q = 0; q < 3; q++) {
+                    bmn[b][q] = fmin_sel(bmn[b][q], A.cl_mn[3 * (size_t)c + q]);
+                    bmx[b][q] = fmax_sel(bmx[b][q], A.cl_mx[3 * (size_t)c + q]);
+                }
+            }
+            sah_sweep_axis(a, bmn, bmx, bc, best_cost, best_axis, best_split);
+        }
+        uint32_t nl = 0;
+        if (best_axis < 0) {
+            nl = j.n / 2;
+        } else {
+            const float ext = cmx[best_axis] - cmn[best_axis];
+            uint32_t w = 0, r = 0;
+            for (uint32_t k = 0; k < j.n; k++) {
+                const uint32_t c = A.idx[j.a + k];
+                const int b = sah_bin((A.cl_mn[3 * (size_t)c + best_axis] + A.cl_mx[3 * (size_t)c + best_axis]) * 0.5f, cmn[best_axis], ext);
+                if (b < best_split) A.idx[j.a + w++] = c;
+                else A.tmp[j.a + r++] = c;
+            }
+            for (uint32_t k = 0; k < r; k++) A.idx[j.a + w + k] = A.tmp[j.a + k];
+            nl = w;
+        }
+        A.rcnt[node] = total > A.T ? total : A.T + 1u;
+        sah_patch_parent(A, j.patch, node);
+        st[sp++] = SahSeg{j.a + nl, j.n - nl, j.pool + nl, (node << 1) | 1u};
+        st[sp++] = SahSeg{j.a, nl, j.pool + 1, node << 1};
+    }
+}
+}  // namespace
+
+// returns hipSuccess and *relinked = false when the tree has fewer than three clusters (nothing to do, like the host path)
+static hipError_t sah_top_relink_gpu(hipStream_t st, uint32_t n, uint32_t nn, uint32_t* left, uint32_t* right, uint32_t* rcnt, uint32_t* pint, uint32_t* pleaf,
+                                     const float* lmin, const float* lmax, const float* nbox, uint32_t T, bool* relinked) {
+    *relinked = false;
+    hipError_t err = hipSuccess;
+    uint32_t *top = nullptr, *ncl = nullptr, *pool_pos = nullptr, *cl_pos = nullptr, *pool = nullptr, *cl_ref = nullptr, *cl_cnt = nullptr, *idx = nullptr, *tmp = nullptr,
+             *counters = nullptr;
+    float *cl_mn = nullptr, *cl_mx = nullptr;
+    SahSeg *seg_a = nullptr, *seg_b = nullptr, *seg_small = nullptr;
+    void* scan_tmp = nullptr;
+    size_t scan_bytes = 0;
+    uint32_t tails[4] = {0, 0, 0, 0}, npool = 0, nc = 0;
+    const unsigned grid = (unsigned)(((uint64_t)nn + 255) / 256 > 4096 ? 4096 : ((uint64_t)nn + 255) / 256);
+#define SAH_CHECK(x)            \
+    do {                        \
+        err = (x);              \
+        if (err != hipSuccess) goto sah_done; \
+    } while (0)
+    SAH_CHECK(hipMalloc(&top, (size_t)nn * 4));
+    SAH_CHECK(hipMalloc(&ncl, (size_t)nn * 4));
+    SAH_CHECK(hipMalloc(&pool_pos, (size_t)nn * 4));
+    SAH_CHECK(hipMalloc(&cl_pos, (size_t)nn * 4));
+    hipLaunchKernelGGL(k_sah_mark, dim3(grid), dim3(256), 0, st, left, right, rcnt, nn, T, top, ncl);
+    SAH_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, top, pool_pos, (int)nn, st));
+    SAH_CHECK(hipMalloc(&scan_tmp, scan_bytes ? scan_bytes : 16));
+    SAH_CHECK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, top, pool_pos, (int)nn, st));
+    SAH_CHECK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, ncl, cl_pos, (int)nn, st));
+    SAH_CHECK(hipMemcpyAsync(&tails[0], pool_pos + (nn - 1), 4, hipMemcpyDeviceToHost, st));
+    SAH_CHECK(hipMemcpyAsync(&tails[1], top + (nn - 1), 4, hipMemcpyDeviceToHost, st));
+    SAH_CHECK(hipMemcpyAsync(&tails[2], cl_pos + (nn - 1), 4, hipMemcpyDeviceToHost, st));
+    SAH_CHECK(hipMemcpyAsync(&tails[3], ncl + (nn - 1), 4, hipMemcpyDeviceToHost, st));
+    SAH_CHECK(hipStreamSynchronize(st));
+    npool = tails[0] + tails[1];
+    nc = tails[2] + tails[3];
+    if (nc < 3 || npool != nc - 1) goto sah_done;  // (the host path's `return false`)
+    (void)n;
+    SAH_CHECK(hipMalloc(&pool, (size_t)npool * 4));
+    SAH_CHECK(hipMalloc(&cl_ref, (size_t)nc * 4));
+    SAH_CHECK(hipMalloc(&cl_cnt, (size_t)nc * 4));
+    SAH_CHECK(hipMalloc(&cl_mn, (size_t)nc * 12));
+    SAH_CHECK(hipMalloc(&cl_mx, (size_t)nc * 12));
+    SAH_CHECK(hipMalloc(&idx, (size_t)nc * 4));
+    SAH_CHECK(hipMalloc(&tmp, (size_t)nc * 4));
+    SAH_CHECK(hipMalloc(&seg_a, 2 * ((size_t)nc / kSahSmall + 2) * sizeof(SahSeg)));  // [huge | big] of the current level
+    SAH_CHECK(hipMalloc(&seg_b, 2 * ((size_t)nc / kSahSmall + 2) * sizeof(SahSeg)));  // ... of the next one
+    SAH_CHECK(hipMalloc(&seg_small, ((size_t)nc / 2 + 2) * sizeof(SahSeg)));
+    SAH_CHECK(hipMalloc(&counters, 64));
+    SAH_CHECK(hipMemsetAsync(counters, 0, 64, st));
+    hipLaunchKernelGGL(k_sah_gather, dim3(grid), dim3(256), 0, st, left, right, rcnt, nn, T, top, pool_pos, cl_pos, lmin, lmax, nbox, pool, cl_ref, cl_cnt, cl_mn, cl_mx, idx);
+    {
+        SahArrays A{left, right, rcnt, pint, pleaf, cl_ref, cl_cnt, cl_mn, cl_mx, pool, idx, tmp, T};
+        const size_t half = (size_t)nc / kSahSmall + 2;
+        const SahSeg root{0, nc, 0, 0xFFFFFFFFu};
+        // counters: [0..2] huge / big segment counts of the level being processed + spare, [4..6] of the next level, [8] small segments
+        uint32_t cnt[3] = {0, 0, 0};
+        cnt[nc > kSahHuge ? 0 : (nc > kSahSmall ? 1 : 2)] = 1;
+        SAH_CHECK(hipMemcpyAsync(nc > kSahHuge ? seg_a : (nc > kSahSmall ? seg_a + half : seg_small), &root, sizeof(root), hipMemcpyHostToDevice, st));
+        SAH_CHECK(hipMemcpyAsync(counters, cnt, 8, hipMemcpyHostToDevice, st));
+        SAH_CHECK(hipMemcpyAsync(counters + 8, &cnt[2], 4, hipMemcpyHostToDevice, st));
+        const bool trace = getenv("RT3_TRACE_BUILD") != nullptr;
+        auto tnow = [] { return std::chrono::steady_clock::now(); };
+        auto tl = tnow();
+        // Levels are launched back to back with grids sized for the most segments a level can hold (workgroups beyond the level's
+        // count return at once); the host looks at the counters only every 24 levels.  A level's segments have more than kSahSmall
+        // (kSahHuge) clusters each, so there are at most nc / kSahSmall (nc / kSahHuge) of them.
+        const uint32_t max_huge = nc / kSahHuge + 1, max_big = nc / kSahSmall + 1;
+        int level = 0, cur = 0;
+        for (;;) {
+            for (int burst = 0; burst < 24; burst++, level++, cur ^= 1) {
+                uint32_t* c_cur = counters + 4 * cur;
+                uint32_t* c_next = counters + 4 * (cur ^ 1);
+                SAH_CHECK(hipMemsetAsync(c_next, 0, 8, st));
+                const SahQueues Q{seg_b, seg_b + half, seg_small, c_next, counters + 8};
+                hipLaunchKernelGGL(k_sah_block<1024>, dim3(max_huge), dim3(1024), 0, st, A, seg_a, c_cur, Q);
+                hipLaunchKernelGGL(k_sah_block<256>, dim3(max_big), dim3(256), 0, st, A, seg_a + half, c_cur + 1, Q);
+                std::swap(seg_a, seg_b);
+            }
+            SAH_CHECK(hipMemcpyAsync(cnt, counters + 4 * cur, 8, hipMemcpyDeviceToHost, st));
+            SAH_CHECK(hipStreamSynchronize(st));
+            if (cnt[0] + cnt[1] == 0) break;
+        }
+        if (trace) {
+            fprintf(stderr, "rt3 build:   SAH block levels (%d launched): %.3f ms\n", level, std::chrono::duration<double, std::milli>(tnow() - tl).count());
+            tl = tnow();
+        }
+        SAH_CHECK(hipMemcpyAsync(&cnt[2], counters + 8, 4, hipMemcpyDeviceToHost, st));
+        SAH_CHECK(hipStreamSynchronize(st));
+        if (cnt[2]) hipLaunchKernelGGL(k_sah_small, dim3((cnt[2] + 63) / 64), dim3(64), 0, st, A, seg_small, cnt[2]);
+        if (trace) {
+            SAH_CHECK(hipStreamSynchronize(st));
+            fprintf(stderr, "rt3 build:   SAH small: %u segments, %.3f ms (%u clusters)\n", cnt[2], std::chrono::duration<double, std::milli>(tnow() - tl).count(), nc);
+        }
+        const uint32_t no_parent = 0xFFFFFFFFu;
+        SAH_CHECK(hipMemcpyAsync(pint, &no_parent, 4, hipMemcpyHostToDevice, st));
+        SAH_CHECK(hipGetLastError());
+        SAH_CHECK(hipStreamSynchronize(st));  // (no_parent / root live on this frame's stack)
+        *relinked = true;
+    }
+sah_done:
+#undef SAH_CHECK
+    for (void* p : {(void*)top, (void*)ncl, (void*)pool_pos, (void*)cl_pos, (void*)pool, (void*)cl_ref, (void*)cl_cnt, (void*)idx, (void*)tmp, (void*)counters,
+                    (void*)cl_mn, (void*)cl_mx, (void*)seg_a, (void*)seg_b, (void*)seg_small, scan_tmp})
+        (void)hipFree(p);
+    return err;
+}
+
 #define LB_CHECK(x)                  \
     do {                             \
         hipError_t e_ = (x);         \
@@ -742,7 +1285,7 @@ bool sah_top_relink(uint32_t nn, uint32_t* left, uint32_t* right, uint32_t* rcnt
 
 hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,
                       const uint32_t* first_prim, uint32_t n, uint32_t leaf_max, uint32_t node_width, uint32_t node_quant, uint32_t collapse_mode,
-                      uint32_t sah_top, LbvhResult* out) {
+                      uint32_t sah_top, uint32_t sah_device, LbvhResult* out) {
     hipError_t err = hipSuccess;
     *out = LbvhResult{};
     out->n_tris = n;
@@ -820,7 +1363,21 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
     } else {
         hipLaunchKernelGGL(k_hierarchy, dim3(grid), dim3(256), 0, st, keys_out, (int)n, left, right, pint, pleaf, rlo, rcnt);
         hipLaunchKernelGGL(k_refit, dim3(grid), dim3(256), 0, st, left, right, pint, pleaf, lmin, lmax, n, nbox, arrive);
-        if (sah_top) {  // re-link the upper tree by SAH on the host, then refit again
+        if (sah_top && sah_device) {  // re-link the upper tree by binned SAH on the GPU (bit-identical to the host path below), then refit again
+            const uint32_t T = sah_top > leaf_max ? sah_top : leaf_max;
+            bool relinked = false;
+            const auto t0 = std::chrono::steady_clock::now();
+            LB_CHECK(sah_top_relink_gpu(st, n, nn, left, right, rcnt, pint, pleaf, lmin, lmax, nbox, T, &relinked));
+            if (relinked) {
+                LB_CHECK(hipMemsetAsync(arrive, 0, (size_t)nn * 4, st));
+                hipLaunchKernelGGL(k_refit, dim3(grid), dim3(256), 0, st, left, right, pint, pleaf, lmin, lmax, n, nbox, arrive);
+            }
+            if (getenv("RT3_TRACE_BUILD")) {
+                LB_CHECK(hipStreamSynchronize(st));
+                fprintf(stderr, "rt3 build: device SAH top (incl. GPU LBVH drain) + second refit %.2f ms\n",
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+            }
+        } else if (sah_top) {  // the same re-link on the host (RT3_OPT_SAH_TOP_DEVICE = 0)
             const uint32_t T = sah_top > leaf_max ? sah_top : leaf_max;
             const bool trace = getenv("RT3_TRACE_BUILD") != nullptr;  // phase times of the host part to stderr
             auto now = [] { return std::chrono::steady_clock::now(); };

@@ -126,6 +126,26 @@ def test_lbvh_sah_top_bit_identical(small, T):
     ctx.close()
 
 
+@pytest.mark.parametrize("T", [2, 5, 200])
+def test_sah_top_device_and_host_builds_are_identical(small, T):
+    """RT3_OPT_SAH_TOP_DEVICE: the binned-SAH top built on the GPU (default; level-synchronous for big segments, one thread per
+    small one) against the same algorithm on the host, and both against the oracle: every reduction in it is a min, a max or an
+    integer sum and the partitions are stable, so the trees are the same arrays bit for bit."""
+    mesh, sky, bn, _ = small
+    osc = orc.Scene(mesh, sah_top=T)
+    out = []
+    for dev in (1, 0):
+        ctx = Context(0)
+        ctx.set_option(L.OPT_SAH_TOP, T)
+        ctx.set_option(L.OPT_SAH_TOP_DEVICE, dev)
+        ctx.upload_mesh(mesh)
+        ctx.build_accel()
+        out.append((ctx.accel_info(), *ctx.accel_download()))
+        ctx.close()
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert np.array_equal(out[0][1], osc.nodes()) and np.array_equal(out[0][2], osc.tris())
+
+
 def test_lbvh_edge_cases():
     """empty scene, one triangle, duplicate triangles (identical Morton codes)."""
     ctx = Context(0)

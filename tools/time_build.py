@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time rt3_accel_build (GPU LBVH + host SAH top + four-wide quantised emit) for the bench scene and a larger one."""
+"""Time rt3_accel_build (GPU LBVH + SAH top on the device or on the host + four-wide quantised emit) for the bench scene and a larger one."""
 import sys
 import time
 from pathlib import Path
@@ -13,12 +13,13 @@ for detail in (1.0, 1.9):
     mesh = scenes.atrium(detail)
     ctx = Context(0)
     ctx.upload_mesh(mesh)
-    for T in (0, 2, 8):
+    for T, dev in ((0, 1), (2, 1), (2, 0), (8, 1)):
         ctx.set_option(L.OPT_SAH_TOP, T)
+        ctx.set_option(L.OPT_SAH_TOP_DEVICE, dev)
         ts = []
         for _ in range(4):
             t0 = time.perf_counter()
             ctx.build_accel()
             ts.append(1e3 * (time.perf_counter() - t0))
-        print(f"atrium({detail}): {mesh.n_triangles} triangles, SAH_TOP {T}: build {min(ts[1:]):.1f} ms (first {ts[0]:.1f})", flush=True)
+        print(f"atrium({detail}): {mesh.n_triangles} triangles, SAH_TOP {T} on the {'GPU' if dev else 'host'}: build {min(ts[1:]):.1f} ms (first {ts[0]:.1f})", flush=True)
     ctx.close()
