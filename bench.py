@@ -334,11 +334,11 @@ def main():
                    "frac": round(sq["valu_per_clk_per_simd"] / 0.5, 4), "wait_any": sq.get("wait_any"), "wait_inst_any": sq.get("wait_inst_any"),
                    "active_inst_any": sq.get("active_inst_any"), "source": prof["_file"] if prof else None}
     # ---- k_shade: the kernel that really is traffic bound.  Streaming bytes it must move per frame (record sizes of DESIGN.md 5):
-    # first bounce: {pixel, blue noise} 8 + depth 4 + G-buffer 16 in, radiance slot 16 out; later bounces: ray 32 + throughput/pdf 16 +
-    # path id 4 + hit 16 in; every extension ray out 52 (ray 32 + throughput/pdf 16 + path id 4), every shadow ray out 40
+    # first bounce: {pixel, blue noise} 8 + depth 4 + G-buffer 16 in, radiance slot 16 out; later bounces: ray records 32 (their .w
+    # carry the path's pdf and id) + throughput 12 + hit 16 in; every extension ray out 44 (ray 32 + throughput 12), every shadow ray out 40
     n_first_paths = float(W * H * args.spp) / world
     later_in = max(float(cst.extension_rays) - float(W * H) / world, 0.0)  # every bounce ray traced is one path vertex shaded afterwards
-    shade_stream = n_first_paths * (28.0 + 16.0) + later_in * 68.0 + later_in * 52.0 + float(cst.shadow_rays) * 40.0
+    shade_stream = n_first_paths * (28.0 + 16.0) + later_in * 60.0 + float(cst.extension_rays - float(W * H) / world) * 44.0 + float(cst.shadow_rays) * 40.0
     shade_ms = st.shade_ms / steps
     shade_gbps = shade_stream / (shade_ms * 1e-3) / 1e9 if shade_ms > 0 else 0.0
     sh_first, sh_later = prof_kernel("rt3::k_shade<true>"), prof_kernel("rt3::k_shade<false>")

@@ -105,7 +105,6 @@ struct rt3_ctx {
     // work queues (capacity in paths)
     size_t cap = 0, cap_pix = 0;
     float *rays[2] = {nullptr, nullptr}, *hits = nullptr, *T[2] = {nullptr, nullptr};
-    uint32_t* pid[2] = {nullptr, nullptr};
     float *sh_rays = nullptr, *sh_contrib = nullptr, *lacc = nullptr, *radsum = nullptr;
     uint32_t* d_counters = nullptr;
     uint32_t counters_cap = 1 << 16, counters_next = 0;
@@ -276,7 +275,7 @@ int sync_textures(rt3_ctx* c) {
 // Failure-atomic: if any allocation fails the whole queue set is released and the capacities drop to 0, so the next pass
 // re-allocates (or reports the error again) instead of launching kernels on a half-resized set.
 void free_work(rt3_ctx* c) {
-    for (int k = 0; k < 2; k++) { dev_free(c->rays[k]); dev_free(c->T[k]); dev_free(c->pid[k]); }
+    for (int k = 0; k < 2; k++) { dev_free(c->rays[k]); dev_free(c->T[k]); }
     dev_free(c->hits); dev_free(c->sh_rays); dev_free(c->sh_contrib); dev_free(c->lacc); dev_free(c->radsum);
     c->cap = 0;
     c->cap_pix = 0;
@@ -288,8 +287,7 @@ int ensure_work(rt3_ctx* c, size_t paths, size_t npix) {
         c->cap = 0;
         for (int k = 0; k < 2 && !r; k++) {
             if (!r) r = dev_alloc(c, &c->rays[k], 8 * P);
-            if (!r) r = dev_alloc(c, &c->T[k], 4 * P);
-            if (!r) r = dev_alloc(c, &c->pid[k], P);
+            if (!r) r = dev_alloc(c, &c->T[k], 3 * P);  // throughput planes (the path's pdf and id ride in the ray records)
         }
         if (!r) r = dev_alloc(c, &c->hits, 4 * P);
         if (!r) r = dev_alloc(c, &c->sh_rays, 8 * P);
@@ -494,9 +492,9 @@ int pass_reference_mode(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y,
             ShadeLaunch L;
             L.g = gd; L.sc = sc; L.pixels = pl->dev; L.pixbn = pl->dev_bn; L.npix = npix; L.width = W; L.s0 = s0; L.bounce = bn;
             L.gbuffer = gb->ptr; L.depth = (const float*)dp->ptr;
-            L.in_rays = c->rays[cur]; L.in_hits = c->hits; L.in_T = c->T[cur]; L.in_pid = c->pid[cur];
+            L.in_rays = c->rays[cur]; L.in_hits = c->hits; L.in_T = c->T[cur];
             L.in_count = bn ? ext_cnt_at(bn - 1) : nullptr; L.n_first = n_first;
-            L.out_rays = c->rays[cur ^ 1]; L.out_T = c->T[cur ^ 1]; L.out_pid = c->pid[cur ^ 1]; L.out_count = ext_cnt_at(bn);
+            L.out_rays = c->rays[cur ^ 1]; L.out_T = c->T[cur ^ 1]; L.out_count = ext_cnt_at(bn);
             L.sh_rays = c->sh_rays; L.sh_contrib = c->sh_contrib; L.sh_count = sh_cnt_at(bn);
             L.lacc = c->lacc; L.stride = S; L.max_n = n_first;
             {
@@ -522,7 +520,7 @@ int pass_reference_mode(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y,
                 if (bn != B - 1) {
                     ScopedTimer t(c, CAT_EXTEND);
                     launch_extend(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->rays[cur], S, ext_cnt_at(bn), 0, n_first, c->hits, nullptr, nullptr,
-                                  c->opt_count ? c->d_totals : nullptr, pool_cur + bn);
+                                  c->opt_count ? c->d_totals : nullptr, pool_cur + bn, true);
                 }
             }
         }

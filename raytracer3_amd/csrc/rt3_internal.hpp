@@ -35,12 +35,10 @@ struct ShadeLaunch {
     const float* in_rays;
     const float* in_hits;
     const float* in_T;
-    const uint32_t* in_pid;
     const uint32_t* in_count;
     uint32_t n_first;
     float* out_rays;
     float* out_T;
-    uint32_t* out_pid;
     uint32_t* out_count;
     float* sh_rays;
     float* sh_contrib;
@@ -53,7 +51,7 @@ struct ShadeLaunch {
 void launch_raygen(hipStream_t st, const GConstDev& g, const uint32_t* pixels, uint32_t npix, float* rays, size_t stride);
 void launch_extend(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float* rays, size_t stride,
                    const uint32_t* count_ptr, uint32_t count_imm, uint32_t max_n, float* hits, uint32_t* cn, uint32_t* ct,
-                   unsigned long long* totals, uint32_t* work_counter);
+                   unsigned long long* totals, uint32_t* work_counter, bool payload = false);
 void launch_shadow(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float* rays, size_t stride,
                    const uint32_t* count_ptr, uint32_t count_imm, uint32_t max_n, const float* contrib, const uint32_t* pid, float* lacc,
                    size_t lstride, uint32_t* occluded_out, uint32_t* cn, uint32_t* ct, unsigned long long* totals, uint32_t* work_counter);

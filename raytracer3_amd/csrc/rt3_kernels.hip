@@ -102,9 +102,11 @@ template <int MODE, bool COUNT, int LAYOUT, typename Finish>
 __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                              const float* __restrict__ rays_a, size_t stride, uint32_t n_a, uint32_t* __restrict__ work_counter_a,
                                              uint32_t* __restrict__ lds, Finish finish, bool any_payload = false,
-                                             const float* __restrict__ rays_b = nullptr, uint32_t n_b = 0, uint32_t* __restrict__ work_counter_b = nullptr) {
+                                             const float* __restrict__ rays_b = nullptr, uint32_t n_b = 0, uint32_t* __restrict__ work_counter_b = nullptr,
+                                             bool ext_payload = false) {
     // any_payload: the any-hit rays come from k_shade's shadow queue, where every ray has the range (kRayTMin, kBackgroundDepth):
-    // the two .w slots of its record carry payload (two contribution channels) instead of tmin / tmax -- 16 bytes less per ray
+    // the two .w slots of its record carry payload (two contribution channels) instead of tmin / tmax -- 16 bytes less per ray.
+    // ext_payload: likewise for the extension rays of the path tracer's own queue (.w = the path's pdf and id, read by k_shade)
     const float* __restrict__ rays = rays_a;
     uint32_t n = n_a;
     uint32_t* __restrict__ work_counter = work_counter_a;
@@ -171,7 +173,7 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
                 const float4 ro = reinterpret_cast<const float4*>(rays)[idx], rd = reinterpret_cast<const float4*>(rays)[stride + idx];
                 r.o = v3(ro.x, ro.y, ro.z);
                 r.d = v3(rd.x, rd.y, rd.z);
-                const bool payload = any_payload && (MODE == 1 || (MODE == 2 && second_pool));
+                const bool payload = (any_payload && (MODE == 1 || (MODE == 2 && second_pool))) || (ext_payload && (MODE == 0 || (MODE == 2 && !second_pool)));
                 r.tmin = payload ? kRayTMin : ro.w;
                 r.best = Hit{payload ? kBackgroundDepth : rd.w, 0.0f, 0.0f, kMiss};
                 r.pay0 = ro.w;
@@ -378,11 +380,11 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(const float4* __restric
                                                          const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
                                                          float* __restrict__ hits, uint32_t* __restrict__ cnt_nodes,
                                                          uint32_t* __restrict__ cnt_tris, unsigned long long* __restrict__ totals,
-                                                         uint32_t* __restrict__ work_counter) {
+                                                         uint32_t* __restrict__ work_counter, int payload) {
     __shared__ uint32_t stack[kLdsStack * kExtendBlock];
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
     unsigned long long tot_n = 0, tot_t = 0;
-    trace_stream<0, COUNT, LAYOUT>(nodes, tris, rays, stride, n, work_counter, stack + threadIdx.x, [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, bool, float, float) {
+    auto finish = [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, bool, float, float) {
         // one 16-byte record per ray: with persistent waves rays finish out of order, four SoA streams would be four
         // scattered partial-line writes
         reinterpret_cast<float4*>(hits)[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
@@ -392,7 +394,8 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(const float4* __restric
             tot_n += cn;
             tot_t += ct;
         }
-    });
+    };
+    trace_stream<0, COUNT, LAYOUT>(nodes, tris, rays, stride, n, work_counter, stack + threadIdx.x, finish, false, nullptr, 0, nullptr, payload != 0);
     if (COUNT && totals) {
         atomicAdd(&totals[0], tot_n);
         atomicAdd(&totals[1], tot_t);
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_trace(const float4* __restrict
                 stt += any ? ct : 0u;
             }
         },
-        true, sh_rays, n_sh, work_sh);
+        true, sh_rays, n_sh, work_sh, true);
     if (COUNT && totals) {
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             atomicAdd(&totals[0], (unsigned long long)n_ext);
@@ -571,14 +574,12 @@ struct ShadeArgs {
     // !FIRST: input queue
     const float* in_rays;
     const float* in_hits;
-    const float* in_T;       // 3 streams + pdf stream
-    const uint32_t* in_pid;
+    const float* in_T;       // throughput: three planes of `stride` floats (the path's pdf and id ride in the .w of its two ray records)
     const uint32_t* in_count;
     uint32_t n_first;        // FIRST: npix * samples_in_batch
     // outputs
     float* out_rays;
     float* out_T;
-    uint32_t* out_pid;
     uint32_t* out_count;
     float* sh_rays;
     float* sh_contrib;
@@ -631,8 +632,13 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(6, 
         hrecord.a = hrecord.b = hrecord.c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         hrecord.rec = a.sc.tri_shade;
         float hbu = 0.0f, hbv = 0.0f;
+        float4 ro = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rd = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+        if (!FIRST && active) {  // ray records {o, pdf} + {d, path id}
+            ro = reinterpret_cast<const float4*>(a.in_rays)[i];
+            rd = reinterpret_cast<const float4*>(a.in_rays)[S + i];
+        }
         if (active) {
-            pid = FIRST ? i : a.in_pid[i];
+            pid = FIRST ? i : __float_as_uint(rd.w);
             sample_in_batch = fast_div(a.npix_div, pid);
             const uint2 pb = a.pixbn[pid - sample_in_batch * a.npix];  // pixel and its blue-noise word in one load
             px = pb.x & 0xFFFFu;
@@ -653,12 +659,10 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(6, 
                 }
             }
         } else if (active) {
-            const float4 ro = reinterpret_cast<const float4*>(a.in_rays)[i], rd = reinterpret_cast<const float4*>(a.in_rays)[S + i];
-            const float4 tp = reinterpret_cast<const float4*>(a.in_T)[i];
             o = v3(ro.x, ro.y, ro.z);
             d = v3(rd.x, rd.y, rd.z);
-            T = v3(tp.x, tp.y, tp.z);
-            pdf_b = tp.w;
+            T = v3(a.in_T[i], a.in_T[S + i], a.in_T[2 * S + i]);
+            pdf_b = ro.w;
             const float4 hrec = reinterpret_cast<const float4*>(a.in_hits)[i];
             uint32_t prim = __float_as_uint(hrec.w);
             if (prim == kMiss) {  // :37-40 ; sky through MIS (north_star)
@@ -780,10 +784,13 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(6, 
         }
         if (emit_ext) {
             const uint32_t j = slot.ext;
-            reinterpret_cast<float4*>(a.out_rays)[j] = make_float4(o.x, o.y, o.z, kRayTMin);  // :31
-            reinterpret_cast<float4*>(a.out_rays)[S + j] = make_float4(nd.x, nd.y, nd.z, kBackgroundDepth);
-            reinterpret_cast<float4*>(a.out_T)[j] = make_float4(Tn.x, Tn.y, Tn.z, pdf_n);
-            a.out_pid[j] = pid;
+            // 44 bytes per extension ray: its range is always (kRayTMin, kBackgroundDepth) (:31), so the .w of its two ray records carry
+            // the path's pdf and id; the throughput follows as three 4-byte planes (queue slots are contiguous per workgroup: coalesced)
+            reinterpret_cast<float4*>(a.out_rays)[j] = make_float4(o.x, o.y, o.z, pdf_n);
+            reinterpret_cast<float4*>(a.out_rays)[S + j] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(pid));
+            a.out_T[j] = Tn.x;
+            a.out_T[S + j] = Tn.y;
+            a.out_T[2 * S + j] = Tn.z;
         }
     }
 }
@@ -987,11 +994,11 @@ void launch_raygen(hipStream_t st, const GConstDev& g, const uint32_t* pixels, u
 }
 void launch_extend(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float* rays, size_t stride,
                    const uint32_t* count_ptr, uint32_t count_imm, uint32_t max_n, float* hits, uint32_t* cn, uint32_t* ct,
-                   unsigned long long* totals, uint32_t* work_counter) {
+                   unsigned long long* totals, uint32_t* work_counter, bool payload) {
     unsigned grid = grid_for(max_n, kExtendBlock, g_trace_max_blocks);
 #define RT3_LAUNCH_EXTEND(C, L)                                                                                                                  \
     hipLaunchKernelGGL((k_extend<C, L>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, hits, cn, ct, totals, \
-                       work_counter)
+                       work_counter, payload ? 1 : 0)
     if (count) {
         if (layout == kLayoutWide48Q) RT3_LAUNCH_EXTEND(true, kLayoutWide48Q);
         else if (layout == kLayoutWide64Q) RT3_LAUNCH_EXTEND(true, kLayoutWide64Q);
@@ -1067,8 +1074,8 @@ void launch_shade(hipStream_t st, bool first, const ShadeLaunch& L) {
     a.npix_div = make_fastdiv(L.npix);
     a.pixbn = L.pixbn;
     a.gbuffer = (const uint4*)L.gbuffer; a.depth = L.depth;
-    a.in_rays = L.in_rays; a.in_hits = L.in_hits; a.in_T = L.in_T; a.in_pid = L.in_pid; a.in_count = L.in_count; a.n_first = L.n_first;
-    a.out_rays = L.out_rays; a.out_T = L.out_T; a.out_pid = L.out_pid; a.out_count = L.out_count;
+    a.in_rays = L.in_rays; a.in_hits = L.in_hits; a.in_T = L.in_T; a.in_count = L.in_count; a.n_first = L.n_first;
+    a.out_rays = L.out_rays; a.out_T = L.out_T; a.out_count = L.out_count;
     a.sh_rays = L.sh_rays; a.sh_contrib = L.sh_contrib; a.sh_count = L.sh_count;
     a.lacc = L.lacc; a.stride = L.stride;
     unsigned grid = grid_for(L.max_n, kShadeBlock, 8192);
