@@ -47,8 +47,11 @@ extern "C" {
 #define RT3_FORMAT_R8G8B8A8_UNORM 37u       /* display image */
 #define RT3_FORMAT_R16_UINT 74u             /* probe ray directions (trace_probes.slang:10, structured_importance_sampling.slang:10) */
 
-/* feature flags carried in GConst.pad[0]; 0 = reference semantics (diffuse BSDF, emissive-only transport,
- * 2 random draws per bounce, refrence_mode.slang:36-57).  The others are north_star additions. */
+/* feature flags carried in GConst.pad[0]; 0 = the reference's estimator (diffuse BSDF, emissive-only transport, 2 random draws
+ * per bounce, refrence_mode.slang:36-57) with ONE documented difference: the reference advances its RNG counter sequentially
+ * (random.slang:49-79), a wavefront needs a closed form and uses counter = (sample * bounces + bounce) * 2 + dim -- the same
+ * numbers whenever no path of the pixel ends early (a closed box), other samples of the same distribution otherwise
+ * (DESIGN.md section 4 item 1).  The other flags are north_star additions. */
 #define RT3_F_NEE_SKY 1u     /* next-event estimation + MIS against the equirect sky */
 #define RT3_F_BLUENOISE 2u   /* Cranley-Patterson shift by resources/bluenoise.png */
 #define RT3_F_SPECULAR 4u    /* layered BSDF: DiffuseBrdf under the GGX SpecularBrdf of brdf.slang:141-311 */

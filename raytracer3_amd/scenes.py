@@ -28,7 +28,7 @@ CORNELL_CAMERA = dict(position=(0.0137, 1.0071, 3.4), direction=(0.0041, -0.0033
 # Fitted to /root/reference/resources/refrence.png (1920x1080): least squares over the eight interior corners of the box as they
 # appear in the image (box interior = the asset's unit cube [-1, 1]^3, open towards +z), no camera roll: 7 px RMS.
 CORNELL_REF_CAMERA = dict(position=(-0.18653, 0.33087, 7.38676), direction=(0.018591, -0.058248, -0.998129), fov_deg=22.8837)
-CORNELL_REF_EMISSION = 0.48  # GeometryInfo.emission of the light cube (x 12 in hit_info); chosen by tools/fit_cornell_ref.py
+CORNELL_REF_EMISSION = 0.48  # GeometryInfo.emission of the light cube (x 12 in hit_info); chosen by tests/experiments/fit_cornell_ref.py
 
 
 def _grid(origin, du, dv, nu, nv, normal=None, disp=None):

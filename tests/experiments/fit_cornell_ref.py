@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Choose the one free photometric parameter of scenes.cornell_ref() -- the emission of its light cube, which the reference's
 processed asset does not carry -- against resources/refrence_480x270.png (a 480x270 copy of the reference tree's only image,
-resources/refrence.png), on the CPU oracle (test infrastructure; the GPU side-by-side is tools/render.py --scene cornell_ref).
+resources/refrence.png), on the CPU oracle (test infrastructure, hence this script lives under tests/; the GPU side-by-side is
+tools/render.py --scene cornell_ref).
 Radiance is linear in the emission, so ONE render with emission 1 is scaled before the display transform.
 Also reports which path depth resembles the image most (the Cycles render looks like direct light only)."""
 import sys
@@ -10,7 +11,7 @@ from pathlib import Path
 import numpy as np
 from PIL import Image
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 import orc  # noqa: E402

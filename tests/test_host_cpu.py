@@ -248,3 +248,21 @@ def test_cornell_ref_is_built_from_the_reference_asset():
     gb, depth = osc.gbuffer(g, threads=2)
     light, _ = osc.reference_mode(g, gb, depth, threads=2)
     assert 0.2 < (depth < 1e5).mean() < 0.5 and light[..., :3].max() > 1.0 and light[0, 0, :3].sum() == 0  # box in the middle, black outside
+
+
+def test_bench_self_launch_refuses_without_devices():
+    """`python bench.py --gpus N` as the driver invokes it starts its ranks itself -- and must fail loudly, before starting any, when
+    the devices are not there (this container has none): no JSON line, a non-zero exit code, a message.  (With devices the same command
+    is covered by the GPU tests: the 3-rank rehearsal and the refusal of more ranks than GPUs.)"""
+    import os
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is visible: covered by the GPU tests")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "no GPU visible" in r.stderr
+    assert not any(ln.startswith("{") for ln in r.stdout.splitlines())
