@@ -18,8 +18,23 @@ mesh, sky, bn = scenes.atrium(1.0), scenes.sky(2048, 1024), assets.load_bluenois
 cam = Camera(scenes.ATRIUM_CAMERA["position"], scenes.ATRIUM_CAMERA["direction"], math.radians(scenes.ATRIUM_CAMERA["fov_deg"]), W / H)
 
 
+import os
+from raytracer3_amd import _lib as L
+
+FUSED = int(os.environ.get("RT3_EXP_FUSED", "-1"))  # -1: library default
+CHUNK = int(os.environ.get("RT3_EXP_CHUNK", "0"))
+BLOCKS = int(os.environ.get("RT3_EXP_BLOCKS", "0"))
+NS = [int(x) for x in os.environ.get("RT3_EXP_N", "2,4,8").split(",")]
+
+
 def timed(rank, n):
     pt = PathTracer((W, H), device=0, rank=rank, n_ranks=n)
+    if FUSED >= 0:
+        pt.ctx.set_option(L.OPT_FUSED_TRACE, FUSED)
+    if CHUNK:
+        pt.ctx.set_option(L.OPT_POOL_CHUNK, CHUNK)
+    if BLOCKS:
+        pt.ctx.set_option(L.OPT_TRACE_BLOCKS, BLOCKS)
     pt.set_scene(mesh, sky, bn)
     best = 1e9
     for rep in range(3):
@@ -35,7 +50,7 @@ def timed(rank, n):
 
 full, rays = timed(0, 1)
 print(f"N=1: {full:.2f} ms, {rays / 1e6:.0f} Mrays")
-for n in (2, 4, 8):
+for n in NS:
     ts = [timed(r, n) for r in range(n)]
     worst = max(t for t, _ in ts)
     print(f"N={n}: per-rank ms " + " ".join(f"{t:.2f}" for t, _ in ts) + f" | slowest {worst:.2f} vs ideal {full / n:.2f} -> efficiency bound {full / n / worst:.3f}"
