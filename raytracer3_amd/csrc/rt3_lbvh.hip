@@ -735,13 +735,14 @@ bool sah_top_relink(uint32_t nn, uint32_t* left, uint32_t* right, uint32_t* rcnt
 // same order, so the tree is bit-identical to the host's and the oracle's -- every reduction in it is a min, a max or an integer
 // sum (exact, order independent), and the partitions are stable.  No bulk D2H / H2D copies: the Karras arrays are re-linked in place.
 //   k_sah_mark / scans / k_sah_gather   top nodes -> pool[] (ascending), their cluster children -> cl_*[] (node order, left first)
-//   k_sah_block  one workgroup per segment of more than kSahSmall clusters, one launch per level: centroid bounds and 3 x 16 bins by
+//   k_sahh_*     segments of more than kSahHuge clusters, tiled over several workgroups: one launch per phase and level
+//   k_sah_block  one workgroup per segment of kSahSmall .. kSahHuge clusters, one launch per level: centroid bounds and 3 x 16 bins by
 //                LDS atomics on order-preserving uints, the split sweep by thread 0, a stable in-place partition in 256-wide chunks
 //   k_sah_small  one thread per remaining segment (<= kSahSmall clusters) running the sequential algorithm with its own stack
 // A subtree over n clusters owns n - 1 pool nodes in pre-order (as on the host), so segments touch disjoint ranges.
 namespace {
 constexpr uint32_t kSahSmall = 16;    // segments of at most this many clusters are finished by one thread
-constexpr uint32_t kSahHuge = 4096;   // segments of more clusters get a 1024-thread workgroup, the others 256 threads
+constexpr uint32_t kSahHuge = 4096;   // segments of more clusters are tiled over several workgroups (k_sahh_*), the others get one of 256 threads
 struct SahSeg { uint32_t a, n, pool, patch; };
 struct SahArrays {
     uint32_t *left, *right, *rcnt, *pint, *pleaf;   // the Karras tree, re-linked in place
@@ -1094,6 +1095,307 @@ __global__ __launch_bounds__(BLOCK) void k_sah_block(SahArrays A, const SahSeg* 
     }
 }
 
+// ---- segments of more than kSahHuge clusters: the same split, tiled over several workgroups (one launch per phase and level).
+// A tile = kSahTile consecutive clusters of one segment; per-segment state lives in global memory and is reduced with atomics on
+// order-preserving uints (min / max) and integers (sums): exact, order independent.
+constexpr uint32_t kSahTile = 2048;
+struct SahHuge {
+    uint32_t cmn[3], cmx[3], total;
+    uint32_t bmn[3][16][3], bmx[3][16][3], bc[3][16];
+    int axis, split;
+    uint32_t nl, tile_base, ntiles;
+};
+struct SahTile { uint32_t seg, t; };
+
+__global__ void k_sahh_tiles(const SahSeg* segs, const uint32_t* n_segs, SahHuge* hs, SahTile* tiles, uint32_t* n_tiles) {
+    const uint32_t s = blockIdx.x;
+    if (s >= *n_segs) return;
+    __shared__ uint32_t s_base;
+    const SahSeg j = segs[s];
+    const uint32_t nt = (j.n + kSahTile - 1) / kSahTile;
+    SahHuge& h = hs[s];
+    for (uint32_t k = threadIdx.x; k < 3 * 16 * 3; k += blockDim.x) {
+        (&h.bmn[0][0][0])[k] = float_to_ordered(INFINITY);
+        (&h.bmx[0][0][0])[k] = float_to_ordered(-INFINITY);
+    }
+    for (uint32_t k = threadIdx.x; k < 3 * 16; k += blockDim.x) (&h.bc[0][0])[k] = 0;
+    if (threadIdx.x < 3) {
+        h.cmn[threadIdx.x] = float_to_ordered(INFINITY);
+        h.cmx[threadIdx.x] = float_to_ordered(-INFINITY);
+    }
+    if (threadIdx.x == 0) {
+        h.total = 0;
+        h.axis = -1;
+        h.split = 0;
+        h.nl = 0;
+        h.ntiles = nt;
+        s_base = atomicAdd(n_tiles, nt);
+        h.tile_base = s_base;
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < nt; t += blockDim.x) tiles[s_base + t] = SahTile{s, t};
+}
+__global__ __launch_bounds__(256) void k_sahh_bounds(SahArrays A, const SahSeg* segs, SahHuge* hs, const SahTile* tiles, const uint32_t* n_tiles) {
+    if (blockIdx.x >= *n_tiles) return;
+    const SahTile tl = tiles[blockIdx.x];
+    const SahSeg j = segs[tl.seg];
+    const uint32_t lo = tl.t * kSahTile, hi = lo + kSahTile < j.n ? lo + kSahTile : j.n;
+    const float inf = INFINITY;
+    float tmn[3] = {inf, inf, inf}, tmx[3] = {-inf, -inf, -inf};
+    uint32_t tc = 0;
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += 256) {
+        const uint32_t c = A.idx[j.a + k];
+        tc += A.cl_cnt[c];
+        for (int a = 0; a < 3; a++) {
+            const float ce = (A.cl_mn[3 * (size_t)c + a] + A.cl_mx[3 * (size_t)c + a]) * 0.5f;
+            tmn[a] = fmin_sel(tmn[a], ce);
+            tmx[a] = fmax_sel(tmx[a], ce);
+        }
+    }
+    tc = wave_sum_u(tc);
+    for (int a = 0; a < 3; a++) {
+        tmn[a] = wave_min_f(tmn[a]);
+        tmx[a] = wave_max_f(tmx[a]);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        SahHuge& h = hs[tl.seg];
+        atomicAdd(&h.total, tc);
+        for (int a = 0; a < 3; a++) {
+            atomicMin(&h.cmn[a], float_to_ordered(tmn[a]));
+            atomicMax(&h.cmx[a], float_to_ordered(tmx[a]));
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_sahh_bins(SahArrays A, const SahSeg* segs, SahHuge* hs, const SahTile* tiles, const uint32_t* n_tiles) {
+    if (blockIdx.x >= *n_tiles) return;
+    __shared__ uint32_t s_bmn[3][16][3], s_bmx[3][16][3], s_bc[3][16];
+    const SahTile tl = tiles[blockIdx.x];
+    const SahSeg j = segs[tl.seg];
+    SahHuge& h = hs[tl.seg];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const float inf = INFINITY;
+    for (uint32_t k = tid; k < 3 * 16 * 3; k += 256) {
+        (&s_bmn[0][0][0])[k] = float_to_ordered(inf);
+        (&s_bmx[0][0][0])[k] = float_to_ordered(-inf);
+    }
+    for (uint32_t k = tid; k < 3 * 16; k += 256) (&s_bc[0][0])[k] = 0;
+    __syncthreads();
+    float cmn[3], ext[3];
+    for (int a = 0; a < 3; a++) {
+        cmn[a] = ordered_to_float(h.cmn[a]);
+        ext[a] = ordered_to_float(h.cmx[a]) - cmn[a];
+    }
+    const uint32_t lo = tl.t * kSahTile, hi = lo + kSahTile < j.n ? lo + kSahTile : j.n;
+    const uint32_t hi_round = lo + ((hi - lo + 63u) & ~63u);  // whole waves iterate: cross-lane reductions inside
+    for (uint32_t k = lo + tid; k < hi_round; k += 256) {
+        const bool valid = k < hi;
+        uint32_t cnt = 0;
+        float mn[3] = {inf, inf, inf}, mx[3] = {-inf, -inf, -inf};
+        if (valid) {
+            const uint32_t c = A.idx[j.a + k];
+            cnt = A.cl_cnt[c];
+            for (int q = 0; q < 3; q++) {
+                mn[q] = A.cl_mn[3 * (size_t)c + q];
+                mx[q] = A.cl_mx[3 * (size_t)c + q];
+            }
+        }
+        for (int a = 0; a < 3; a++) {
+            if (!(ext[a] > 0.0f)) continue;
+            const int b = valid ? sah_bin((mn[a] + mx[a]) * 0.5f, cmn[a], ext[a]) : -1;
+            unsigned long long todo = __ballot(valid);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int bb = __shfl(b, leader);
+                const bool mine = b == bb;
+                const unsigned long long peers = __ballot(mine);
+                const uint32_t sc = wave_sum_u(mine ? cnt : 0u);
+                float rmn[3], rmx[3];
+                for (int q = 0; q < 3; q++) {
+                    rmn[q] = wave_min_f(mine ? mn[q] : inf);
+                    rmx[q] = wave_max_f(mine ? mx[q] : -inf);
+                }
+                if ((int)lane == leader) {
+                    atomicAdd(&s_bc[a][bb], sc);
+                    for (int q = 0; q < 3; q++) {
+                        atomicMin(&s_bmn[a][bb][q], float_to_ordered(rmn[q]));
+                        atomicMax(&s_bmx[a][bb][q], float_to_ordered(rmx[q]));
+                    }
+                }
+                todo &= ~peers;
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < 3 * 16 * 3; k += 256) {  // this tile's bins into the segment's
+        const uint32_t vmn = (&s_bmn[0][0][0])[k], vmx = (&s_bmx[0][0][0])[k];
+        if (vmn != float_to_ordered(inf)) atomicMin(&(&h.bmn[0][0][0])[k], vmn);
+        if (vmx != float_to_ordered(-inf)) atomicMax(&(&h.bmx[0][0][0])[k], vmx);
+    }
+    for (uint32_t k = tid; k < 3 * 16; k += 256)
+        if ((&s_bc[0][0])[k]) atomicAdd(&(&h.bc[0][0])[k], (&s_bc[0][0])[k]);
+}
+__global__ __launch_bounds__(64) void k_sahh_pick(const SahSeg* segs, const uint32_t* n_segs, SahHuge* hs) {
+    const uint32_t s = blockIdx.x;
+    if (s >= *n_segs) return;
+    __shared__ float s_cost[3][16];
+    SahHuge& h = hs[s];
+    const uint32_t tid = threadIdx.x;
+    const float inf = INFINITY;
+    float ext[3];
+    for (int a = 0; a < 3; a++) ext[a] = ordered_to_float(h.cmx[a]) - ordered_to_float(h.cmn[a]);
+    if (tid < 48) {
+        const int a = (int)tid >> 4, sp = (int)tid & 15;
+        float cost = inf;
+        if (sp >= 1 && ext[a] > 0.0f) {
+            float lmn[3] = {inf, inf, inf}, lmx[3] = {-inf, -inf, -inf}, rmn[3] = {inf, inf, inf}, rmx[3] = {-inf, -inf, -inf};
+            uint32_t lc = 0, rc = 0;
+            for (int b = 0; b < sp; b++) {
+                lc += h.bc[a][b];
+                for (int q = 0; q < 3; q++) {
+                    lmn[q] = fmin_sel(lmn[q], ordered_to_float(h.bmn[a][b][q]));
+                    lmx[q] = fmax_sel(lmx[q], ordered_to_float(h.bmx[a][b][q]));
+                }
+            }
+            for (int b = 15; b >= sp; b--) {
+                rc += h.bc[a][b];
+                for (int q = 0; q < 3; q++) {
+                    rmn[q] = fmin_sel(rmn[q], ordered_to_float(h.bmn[a][b][q]));
+                    rmx[q] = fmax_sel(rmx[q], ordered_to_float(h.bmx[a][b][q]));
+                }
+            }
+            if (lc != 0 && rc != 0) cost = sah_half_area(lmn, lmx) * (float)lc + sah_half_area(rmn, rmx) * (float)rc;
+        }
+        s_cost[a][sp] = cost;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float best_cost = inf;
+        int best_axis = -1, best_split = 0;
+        for (int a = 0; a < 3; a++)
+            for (int sp = 1; sp < 16; sp++)
+                if (s_cost[a][sp] < best_cost) {
+                    best_cost = s_cost[a][sp];
+                    best_axis = a;
+                    best_split = sp;
+                }
+        h.axis = best_axis;
+        h.split = best_split;
+        if (best_axis < 0) h.nl = segs[s].n / 2;
+    }
+}
+// lefts of every tile (axis >= 0 only)
+__global__ __launch_bounds__(256) void k_sahh_count(SahArrays A, const SahSeg* segs, const SahHuge* hs, const SahTile* tiles, const uint32_t* n_tiles, uint32_t* tile_left) {
+    if (blockIdx.x >= *n_tiles) return;
+    __shared__ uint32_t s_n;
+    const SahTile tl = tiles[blockIdx.x];
+    const SahSeg j = segs[tl.seg];
+    const SahHuge& h = hs[tl.seg];
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    if (h.axis >= 0) {
+        const float cmn = ordered_to_float(h.cmn[h.axis]), ext = ordered_to_float(h.cmx[h.axis]) - cmn;
+        const uint32_t lo = tl.t * kSahTile, hi = lo + kSahTile < j.n ? lo + kSahTile : j.n;
+        uint32_t n = 0;
+        for (uint32_t k = lo + threadIdx.x; k < hi; k += 256) {
+            const uint32_t c = A.idx[j.a + k];
+            const float ce = (A.cl_mn[3 * (size_t)c + h.axis] + A.cl_mx[3 * (size_t)c + h.axis]) * 0.5f;
+            n += sah_bin(ce, cmn, ext) < h.split ? 1u : 0u;
+        }
+        n = wave_sum_u(n);
+        if ((threadIdx.x & 63u) == 0) atomicAdd(&s_n, n);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) tile_left[blockIdx.x] = s_n;
+}
+// per segment: exclusive offsets of its tiles' lefts / rights, and the number of lefts
+__global__ void k_sahh_scan(const SahSeg* segs, const uint32_t* n_segs, SahHuge* hs, const uint32_t* tile_left, uint32_t* tile_woff, uint32_t* tile_roff) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= *n_segs) return;
+    SahHuge& h = hs[s];
+    if (h.axis < 0) return;
+    const SahSeg j = segs[s];
+    uint32_t w = 0, r = 0;
+    for (uint32_t t = 0; t < h.ntiles; t++) {
+        const uint32_t lo = t * kSahTile, hi = lo + kSahTile < j.n ? lo + kSahTile : j.n;
+        const uint32_t l = tile_left[h.tile_base + t];
+        tile_woff[h.tile_base + t] = w;
+        tile_roff[h.tile_base + t] = r;
+        w += l;
+        r += (hi - lo) - l;
+    }
+    h.nl = w;
+}
+// stable scatter of a tile into tmp at its final positions: lefts at a + woff.., rights at a + nl + roff..
+__global__ __launch_bounds__(256) void k_sahh_scatter(SahArrays A, const SahSeg* segs, const SahHuge* hs, const SahTile* tiles, const uint32_t* n_tiles, const uint32_t* tile_woff,
+                                                      const uint32_t* tile_roff) {
+    if (blockIdx.x >= *n_tiles) return;
+    __shared__ uint32_t s_w, s_r, s_wave[4][2];
+    const SahTile tl = tiles[blockIdx.x];
+    const SahSeg j = segs[tl.seg];
+    const SahHuge& h = hs[tl.seg];
+    if (h.axis < 0) return;  // halved in index order: nothing moves
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const float cmn = ordered_to_float(h.cmn[h.axis]), ext = ordered_to_float(h.cmx[h.axis]) - cmn;
+    const uint32_t lo = tl.t * kSahTile, hi = lo + kSahTile < j.n ? lo + kSahTile : j.n;
+    if (tid == 0) {
+        s_w = tile_woff[blockIdx.x];
+        s_r = tile_roff[blockIdx.x];
+    }
+    __syncthreads();
+    for (uint32_t base = lo; base < hi; base += 256) {
+        const uint32_t k = base + tid;
+        const bool valid = k < hi;
+        uint32_t c = 0;
+        bool goes_left = false;
+        if (valid) {
+            c = A.idx[j.a + k];
+            const float ce = (A.cl_mn[3 * (size_t)c + h.axis] + A.cl_mx[3 * (size_t)c + h.axis]) * 0.5f;
+            goes_left = sah_bin(ce, cmn, ext) < h.split;
+        }
+        const unsigned long long ml = __ballot(valid && goes_left), mr = __ballot(valid && !goes_left);
+        if (lane == 0) {
+            s_wave[wave][0] = (uint32_t)__popcll(ml);
+            s_wave[wave][1] = (uint32_t)__popcll(mr);
+        }
+        __syncthreads();
+        uint32_t wl = s_w, wr = s_r;
+        for (uint32_t q = 0; q < wave; q++) {
+            wl += s_wave[q][0];
+            wr += s_wave[q][1];
+        }
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (valid) {
+            if (goes_left) A.tmp[j.a + wl + (uint32_t)__popcll(ml & below)] = c;
+            else A.tmp[j.a + h.nl + wr + (uint32_t)__popcll(mr & below)] = c;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            s_w += s_wave[0][0] + s_wave[1][0] + s_wave[2][0] + s_wave[3][0];
+            s_r += s_wave[0][1] + s_wave[1][1] + s_wave[2][1] + s_wave[3][1];
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_sahh_copy(SahArrays A, const SahSeg* segs, const SahHuge* hs, const SahTile* tiles, const uint32_t* n_tiles) {
+    if (blockIdx.x >= *n_tiles) return;
+    const SahTile tl = tiles[blockIdx.x];
+    const SahSeg j = segs[tl.seg];
+    if (hs[tl.seg].axis < 0) return;
+    const uint32_t lo = tl.t * kSahTile, hi = lo + kSahTile < j.n ? lo + kSahTile : j.n;
+    for (uint32_t k = lo + threadIdx.x; k < hi; k += 256) A.idx[j.a + k] = A.tmp[j.a + k];
+}
+__global__ void k_sahh_emit(SahArrays A, const SahSeg* segs, const uint32_t* n_segs, const SahHuge* hs, SahQueues Q) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= *n_segs) return;
+    const SahSeg j = segs[s];
+    const SahHuge& h = hs[s];
+    const uint32_t node = A.pool[j.pool], nl = h.nl, total = h.total;
+    A.rcnt[node] = total > A.T ? total : A.T + 1u;
+    sah_patch_parent(A, j.patch, node);
+    sah_emit_child(A, SahSeg{j.a, nl, j.pool + 1, node << 1}, Q);
+    sah_emit_child(A, SahSeg{j.a + nl, j.n - nl, j.pool + nl, (node << 1) | 1u}, Q);
+}
+
 // one thread per segment of at most kSahSmall clusters: sah_top_relink's loop, with a private stack
 __global__ void k_sah_small(SahArrays A, const SahSeg* segs, uint32_t n_segs) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1177,6 +1479,9 @@ static hipError_t sah_top_relink_gpu(hipStream_t st, uint32_t n, uint32_t nn, ui
              *counters = nullptr;
     float *cl_mn = nullptr, *cl_mx = nullptr;
     SahSeg *seg_a = nullptr, *seg_b = nullptr, *seg_small = nullptr;
+    SahHuge* hs = nullptr;
+    SahTile* tiles = nullptr;
+    uint32_t *tile_left = nullptr, *tile_woff = nullptr, *tile_roff = nullptr;
     void* scan_tmp = nullptr;
     size_t scan_bytes = 0;
     uint32_t tails[4] = {0, 0, 0, 0}, npool = 0, nc = 0;
@@ -1216,6 +1521,14 @@ static hipError_t sah_top_relink_gpu(hipStream_t st, uint32_t n, uint32_t nn, ui
     SAH_CHECK(hipMalloc(&seg_small, ((size_t)nc / 2 + 2) * sizeof(SahSeg)));
     SAH_CHECK(hipMalloc(&counters, 64));
     SAH_CHECK(hipMemsetAsync(counters, 0, 64, st));
+    {
+        const size_t mh = (size_t)nc / kSahHuge + 1, mt = (size_t)nc / kSahTile + mh + 1;
+        SAH_CHECK(hipMalloc(&hs, mh * sizeof(SahHuge)));
+        SAH_CHECK(hipMalloc(&tiles, mt * sizeof(SahTile)));
+        SAH_CHECK(hipMalloc(&tile_left, mt * 4));
+        SAH_CHECK(hipMalloc(&tile_woff, mt * 4));
+        SAH_CHECK(hipMalloc(&tile_roff, mt * 4));
+    }
     hipLaunchKernelGGL(k_sah_gather, dim3(grid), dim3(256), 0, st, left, right, rcnt, nn, T, top, pool_pos, cl_pos, lmin, lmax, nbox, pool, cl_ref, cl_cnt, cl_mn, cl_mx, idx);
     {
         SahArrays A{left, right, rcnt, pint, pleaf, cl_ref, cl_cnt, cl_mn, cl_mx, pool, idx, tmp, T};
@@ -1233,21 +1546,35 @@ static hipError_t sah_top_relink_gpu(hipStream_t st, uint32_t n, uint32_t nn, ui
         // Levels are launched back to back with grids sized for the most segments a level can hold (workgroups beyond the level's
         // count return at once); the host looks at the counters only every 24 levels.  A level's segments have more than kSahSmall
         // (kSahHuge) clusters each, so there are at most nc / kSahSmall (nc / kSahHuge) of them.
-        const uint32_t max_huge = nc / kSahHuge + 1, max_big = nc / kSahSmall + 1;
+        const uint32_t max_huge = nc / kSahHuge + 1, max_big = nc / kSahSmall + 1, max_tiles = nc / kSahTile + max_huge + 1;
+        bool huge_possible = nc > kSahHuge;  // (checked again with the counters after every burst of levels)
         int level = 0, cur = 0;
         for (;;) {
-            for (int burst = 0; burst < 24; burst++, level++, cur ^= 1) {
+            for (int burst = 0; burst < (huge_possible ? 8 : 24); burst++, level++, cur ^= 1) {
                 uint32_t* c_cur = counters + 4 * cur;
                 uint32_t* c_next = counters + 4 * (cur ^ 1);
                 SAH_CHECK(hipMemsetAsync(c_next, 0, 8, st));
                 const SahQueues Q{seg_b, seg_b + half, seg_small, c_next, counters + 8};
-                hipLaunchKernelGGL(k_sah_block<1024>, dim3(max_huge), dim3(1024), 0, st, A, seg_a, c_cur, Q);
+                if (huge_possible) {  // segments of more than kSahHuge clusters, tiled over several workgroups: one launch per phase
+                    uint32_t* n_tiles = counters + 12;
+                    SAH_CHECK(hipMemsetAsync(n_tiles, 0, 4, st));
+                    hipLaunchKernelGGL(k_sahh_tiles, dim3(max_huge), dim3(64), 0, st, seg_a, c_cur, hs, tiles, n_tiles);
+                    hipLaunchKernelGGL(k_sahh_bounds, dim3(max_tiles), dim3(256), 0, st, A, seg_a, hs, tiles, n_tiles);
+                    hipLaunchKernelGGL(k_sahh_bins, dim3(max_tiles), dim3(256), 0, st, A, seg_a, hs, tiles, n_tiles);
+                    hipLaunchKernelGGL(k_sahh_pick, dim3(max_huge), dim3(64), 0, st, seg_a, c_cur, hs);
+                    hipLaunchKernelGGL(k_sahh_count, dim3(max_tiles), dim3(256), 0, st, A, seg_a, hs, tiles, n_tiles, tile_left);
+                    hipLaunchKernelGGL(k_sahh_scan, dim3((max_huge + 63) / 64), dim3(64), 0, st, seg_a, c_cur, hs, tile_left, tile_woff, tile_roff);
+                    hipLaunchKernelGGL(k_sahh_scatter, dim3(max_tiles), dim3(256), 0, st, A, seg_a, hs, tiles, n_tiles, tile_woff, tile_roff);
+                    hipLaunchKernelGGL(k_sahh_copy, dim3(max_tiles), dim3(256), 0, st, A, seg_a, hs, tiles, n_tiles);
+                    hipLaunchKernelGGL(k_sahh_emit, dim3((max_huge + 63) / 64), dim3(64), 0, st, A, seg_a, c_cur, hs, Q);
+                }
                 hipLaunchKernelGGL(k_sah_block<256>, dim3(max_big), dim3(256), 0, st, A, seg_a + half, c_cur + 1, Q);
                 std::swap(seg_a, seg_b);
             }
             SAH_CHECK(hipMemcpyAsync(cnt, counters + 4 * cur, 8, hipMemcpyDeviceToHost, st));
             SAH_CHECK(hipStreamSynchronize(st));
             if (cnt[0] + cnt[1] == 0) break;
+            huge_possible = cnt[0] > 0;
         }
         if (trace) {
             fprintf(stderr, "rt3 build:   SAH block levels (%d launched): %.3f ms\n", level, std::chrono::duration<double, std::milli>(tnow() - tl).count());
@@ -1269,7 +1596,8 @@ static hipError_t sah_top_relink_gpu(hipStream_t st, uint32_t n, uint32_t nn, ui
 sah_done:
 #undef SAH_CHECK
     for (void* p : {(void*)top, (void*)ncl, (void*)pool_pos, (void*)cl_pos, (void*)pool, (void*)cl_ref, (void*)cl_cnt, (void*)idx, (void*)tmp, (void*)counters,
-                    (void*)cl_mn, (void*)cl_mx, (void*)seg_a, (void*)seg_b, (void*)seg_small, scan_tmp})
+                    (void*)cl_mn, (void*)cl_mx, (void*)seg_a, (void*)seg_b, (void*)seg_small, scan_tmp, (void*)hs, (void*)tiles, (void*)tile_left, (void*)tile_woff,
+                    (void*)tile_roff})
         (void)hipFree(p);
     return err;
 }
