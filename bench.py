@@ -18,7 +18,8 @@ Extra objects on the JSON line:
                with this run) over the live HIP-event launch time, against the 8 TB/s HBM3E peak -- a fraction that cannot
                exceed 1.  The ALGORITHMIC bytes of SURVEY 8d (48 + node_bytes n_nodes + 48 n_tris per ray) are reported
                beside it: the BVH is cache resident, so that figure is a cache-side gather rate, not HBM traffic, and is
-               priced against the measured L2 / Infinity-Cache gather rates instead.  `binding` says what the counters show
+               priced against the measured rate of a pointer-chasing gather instead (profiles/r02_gather_cap.md: 9.65 TB/s of requested
+               bytes from any cache level).  `binding` says what the counters show
                the kernel is limited by; `k_shade` carries the same for the one kernel that really is traffic bound.
   cpu_baseline the CPU oracle (a port; the reference cannot be built here) path tracing a centred crop of the same
                frame on the host cores; the crop also yields rmse_vs_oracle
@@ -288,6 +289,8 @@ def main():
     else:
         dom_name, dom_rays, dom_bytes, dom_ms, dom_launches = "k_extend", float(cst.extension_rays), ext_bytes, st.extend_ms / steps, st.extend_launches / steps
     algo_gbps = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    dom_steps = float(cst.trace_nodes[0] + cst.trace_nodes[1] + cst.trace_tris[0] + cst.trace_tris[1]) if fused else float(cst.nodes_visited + cst.tris_tested)
+    requested_gbps = (32.0 * dom_rays + 64.0 * dom_steps) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     trav_ms = (st.trace_ms + st.extend_ms + st.shadow_ms) / steps  # every traversal launch of the frame
     peak = 8000.0
     launches = max(dom_launches, 1)
@@ -360,8 +363,12 @@ def main():
         # gathers; the comparable ceilings are the measured gather rates (MI355X_MICROARCH.md: 8.6 TB/s from the Infinity Cache,
         # 16.8-18.8 TB/s from L2), not the 8 TB/s of HBM
         "algorithmic": {"bytes_per_launch": round(dom_bytes / launches), "GBps": round(algo_gbps, 1), "over_hbm_peak": round(algo_gbps / peak, 4),
-                        "frac_of_l2_gather_peak": round(algo_gbps / 17800.0, 4), "over_infinity_cache_gather_peak": round(algo_gbps / 8600.0, 4),
-                        "bytes_per_ray_formula": f"48 + {node_bytes}*n_nodes + 48*n_tris"},
+                        "bytes_per_ray_formula": f"48 + {node_bytes}*n_nodes + 48*n_tris",
+                        # what the lanes REQUEST from the vector-memory path: 32 B ray + 64 B per step (a step issues 4 x 16 B, node or triangle)
+                        "requested_GBps": round(requested_gbps, 1), "gather_rate_of_the_microbenchmark_GBps": 9650.0,
+                        "ratio_to_that_rate": round(requested_gbps / 9650.0, 3),
+                        "note": "profiles/r02_gather_cap.md: a pointer-chasing gather returns at most ~9.65 TB/s of requested bytes (15.7 B/clk/CU) from any cache level; "
+                                "k_extend sits at that rate -- it, not HBM, is the memory-side ceiling of the traversal"},
         "binding": binding,
         "launches_per_frame": dom_launches, "avg_launch_ms": round(avg_ms, 4), "rays_per_launch": round(dom_rays / launches),
         "bvh": {"nodes": n_nodes, "node_bytes": node_bytes, "tris": n_tris, "levels": levels},

@@ -40,13 +40,15 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(d, h.data(), (size_t)n * 128, hipMemcpyHostToDevice));
     const int steps = 64, blocks = 256 * 24;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int nl : {1, 2, 4, 8}) {
+    for (int nl : {1, 2, 4, 5, 6, 8}) {
         for (int rep = 0; rep < 2; rep++) {
             CK(hipEventRecord(e0));
             for (int it = 0; it < 5; it++) {
                 if (nl == 1) hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, d, n - 1, steps, out);
                 if (nl == 2) hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, d, n - 1, steps, out);
                 if (nl == 4) hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, d, n - 1, steps, out);
+                if (nl == 5) hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(256), 0, 0, d, n - 1, steps, out);
+                if (nl == 6) hipLaunchKernelGGL(k<6>, dim3(blocks), dim3(256), 0, 0, d, n - 1, steps, out);
                 if (nl == 8) hipLaunchKernelGGL(k<8>, dim3(blocks), dim3(256), 0, 0, d, n - 1, steps, out);
             }
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
