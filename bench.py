@@ -219,13 +219,18 @@ def main():
     if args.fused_trace >= 0:
         pt.ctx.set_option(L.OPT_FUSED_TRACE, args.fused_trace)
     pt.set_scene(mesh, sky, bn)
-    if world > 1 and backend == "nccl":
+    if world > 1:
         # librt3's own RCCL communicator: rank 0's unique id travels through the process group's key-value store (the C ABI opens
-        # no sockets; a Rust host would carry the 128 bytes over whatever channel it has)
+        # no sockets; a Rust host would carry the 128 bytes over whatever channel it has).  The id exchange also runs in the gloo
+        # rehearsal, so that everything but ncclCommInitRank / the exchange itself is exercised on a one-GPU box.
         store = dist.distributed_c10d._get_default_store()
         if rank == 0:
             store.set("rt3_comm_unique_id", pt.ctx.comm_unique_id())
-        pt.init_comm(bytes(store.get("rt3_comm_unique_id")))
+        uid = bytes(store.get("rt3_comm_unique_id"))
+        if len(uid) != L.COMM_ID_BYTES:
+            raise SystemExit(f"bench.py: rank {rank} received a {len(uid)}-byte communicator id")
+        if backend == "nccl":
+            pt.init_comm(uid)
     if args.batch_spp:
         pt.ctx.set_option(L.OPT_BATCH_SPP, args.batch_spp)
     cam = Camera(scenes.ATRIUM_CAMERA["position"], scenes.ATRIUM_CAMERA["direction"], math.radians(scenes.ATRIUM_CAMERA["fov_deg"]), W / H)
@@ -333,7 +338,7 @@ def main():
     binding = None
     if sq.get("valu_per_clk_per_simd") is not None and not ke.get("stale_or_missing"):
         # a wave64 VALU instruction holds its SIMD-32 for two cycles: the issue ceiling is 0.5 per clock per SIMD
-        binding = {"bound": "valu_issue+cache_latency", "achieved": sq["valu_per_clk_per_simd"], "peak": 0.5, "unit": "wave VALU instr / clk / SIMD",
+        binding = {"bound": "valu_issue + vector-memory gather rate (see algorithmic.requested_GBps)", "achieved": sq["valu_per_clk_per_simd"], "peak": 0.5, "unit": "wave VALU instr / clk / SIMD",
                    "frac": round(sq["valu_per_clk_per_simd"] / 0.5, 4), "wait_any": sq.get("wait_any"), "wait_inst_any": sq.get("wait_inst_any"),
                    "active_inst_any": sq.get("active_inst_any"), "source": prof["_file"] if prof else None}
     # ---- k_shade: the kernel that really is traffic bound.  Streaming bytes it must move per frame (record sizes of DESIGN.md 5):

@@ -753,6 +753,43 @@ def test_rccl_communicator_single_rank(small):
     pt.close()
 
 
+def test_rccl_rendezvous_of_two_processes(tmp_path):
+    """As far as one GPU lets the multi-rank path go: two PROCESSES, each with its own context on GPU 0, carry rank 0's unique id
+    over a file and both call rt3_comm_init(id, rank, 2).  RCCL's bootstrap must bring the two together -- and then refuse, on
+    BOTH ranks, because they sit on the same device ("Duplicate GPU detected", RCCL cannot place two ranks on one GPU): the ABI
+    reports that as RT3_E_COMM with RCCL's text instead of hanging or aborting.  The exchange itself needs N GPUs."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    code = (
+        "import sys, os, time, ctypes as C\n"
+        f"sys.path.insert(0, {str(root)!r})\n"
+        "from raytracer3_amd.render_graph import Context\n"
+        "r = int(sys.argv[1]); path = sys.argv[2]\n"
+        "ctx = Context(0)\n"
+        "if r == 0:\n"
+        "    uid = ctx.comm_unique_id(); open(path + '.tmp', 'wb').write(uid); os.rename(path + '.tmp', path)\n"
+        "else:\n"
+        "    t0 = time.time()\n"
+        "    while not os.path.exists(path) and time.time() - t0 < 60: time.sleep(0.05)\n"
+        "    uid = open(path, 'rb').read()\n"
+        "rc = ctx.lib.rt3_comm_init(ctx.h, C.c_char_p(uid), r, 2)\n"
+        "print('RESULT', r, rc, ctx.lib.rt3_last_error(ctx.h).decode())\n"
+    )
+    uid_file = str(tmp_path / "uid.bin")
+    env = dict(os.environ, NCCL_DEBUG="WARN")
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), uid_file], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in (0, 1)]
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for r, out in enumerate(outs):
+        line = [ln for ln in out.splitlines() if ln.startswith("RESULT")]
+        assert line, out[-1500:]
+        assert line[-1].split()[1:3] == [str(r), str(L.E_COMM)] and "ncclCommInitRank" in line[-1], line[-1]
+    assert any("uplicate GPU" in o for o in outs), outs[0][-1500:]
+
+
 def test_lbvh_large_scene_bit_identical():
     """0.9 M triangles (atrium at 3x tessellation): GPU build (Morton sort, Karras hierarchy, refit, host SAH top, collapse,
     quantisation) against the oracle's arrays, and 100 k rays with their visit counts."""
