@@ -428,7 +428,7 @@ int pass_gbuffer(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y, const 
     if (int r = reserve_counters(c, 1, &wc_slot)) return r;  // ray-pool cursor of the launch
     {
         ScopedTimer t(c, CAT_EXTEND);
-        launch_extend(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->rays[0], S, nullptr, pl->count, pl->count, c->hits, nullptr, nullptr,
+        launch_extend(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->bvh.top, c->bvh.n_top, c->rays[0], S, nullptr, pl->count, pl->count, c->hits, nullptr, nullptr,
                       c->opt_count ? c->d_totals : nullptr, c->d_counters + wc_slot);
     }
     c->primary_rays_pending += pl->count;
@@ -509,17 +509,17 @@ int pass_reference_mode(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y,
             const bool fuse = c->opt_fused_trace == 1;
             if (nee && bn != B - 1 && fuse) {
                 ScopedTimer t(c, CAT_TRACE);
-                launch_trace(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->rays[cur], c->sh_rays, S, ext_cnt_at(bn), sh_cnt_at(bn), n_first,
+                launch_trace(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->bvh.top, c->bvh.n_top, c->rays[cur], c->sh_rays, S, ext_cnt_at(bn), sh_cnt_at(bn), n_first,
                              c->hits, c->sh_contrib, c->lacc, c->opt_count ? c->d_totals + 4 : nullptr, pool_cur + bn, pool_cur + B + bn);
             } else {
                 if (nee) {
                     ScopedTimer t(c, CAT_SHADOW);
-                    launch_shadow(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->sh_rays, S, sh_cnt_at(bn), 0, n_first, c->sh_contrib, nullptr,
+                    launch_shadow(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->bvh.top, c->bvh.n_top, c->sh_rays, S, sh_cnt_at(bn), 0, n_first, c->sh_contrib, nullptr,
                                   c->lacc, S, nullptr, nullptr, nullptr, c->opt_count ? c->d_totals + 2 : nullptr, pool_cur + B + bn);
                 }
                 if (bn != B - 1) {
                     ScopedTimer t(c, CAT_EXTEND);
-                    launch_extend(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->rays[cur], S, ext_cnt_at(bn), 0, n_first, c->hits, nullptr, nullptr,
+                    launch_extend(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->bvh.top, c->bvh.n_top, c->rays[cur], S, ext_cnt_at(bn), 0, n_first, c->hits, nullptr, nullptr,
                                   c->opt_count ? c->d_totals : nullptr, pool_cur + bn, true);
                 }
             }
@@ -608,7 +608,7 @@ int pass_trace_probes(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y, c
     if (int r = reserve_counters(c, 1, &wc_slot)) return r;
     {
         ScopedTimer t(c, CAT_EXTEND);
-        launch_extend(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->rays[0], S, nullptr, n, n, c->hits, nullptr, nullptr,
+        launch_extend(c->stream, c->opt_count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->bvh.top, c->bvh.n_top, c->rays[0], S, nullptr, n, n, c->hits, nullptr, nullptr,
                       c->opt_count ? c->d_totals : nullptr, c->d_counters + wc_slot);
     }
     c->primary_rays_pending += n;
@@ -691,7 +691,7 @@ void rt3_destroy(rt3_ctx* c) {
     dev_free(c->d_verts); dev_free(c->d_indices); dev_free(c->d_geoms); dev_free(c->d_prim_geom); dev_free(c->d_first_prim);
     dev_free(c->d_tex_pixels); dev_free(c->d_tex_table); dev_free(c->d_srgb_lut);
     dev_free(c->d_sky); dev_free(c->d_sky_alias); dev_free(c->d_cdf_marg); dev_free(c->d_bn);
-    dev_free(c->bvh.nodes); dev_free(c->bvh.tris); dev_free(c->bvh.tri_shade); dev_free(c->d_guide_marg);
+    dev_free(c->bvh.nodes); dev_free(c->bvh.tris); dev_free(c->bvh.tri_shade); dev_free(c->bvh.top); dev_free(c->d_guide_marg);
     for (auto& r : c->resources)
         if (r.owned && r.ptr) (void)hipFree(r.ptr);
     for (auto& p : c->pixlists) {
@@ -1037,6 +1037,7 @@ int rt3_accel_build(rt3_ctx* c, uint32_t* out_handle) {
     dev_free(c->bvh.nodes);
     dev_free(c->bvh.tris);
     dev_free(c->bvh.tri_shade);
+    dev_free(c->bvh.top);
     hipError_t e = lbvh_build(c->stream, c->d_verts, c->d_indices, c->d_geoms, c->d_prim_geom, c->d_first_prim, c->n_prims, c->opt_leaf_size,
                               c->opt_node_width, c->opt_node_quant, c->opt_collapse, c->opt_sah_top, c->opt_sah_device, &c->bvh);
     if (e != hipSuccess) return fail(c, RT3_E_HIP, std::string("lbvh_build: ") + hipGetErrorString(e));
@@ -1046,6 +1047,7 @@ int rt3_accel_build(rt3_ctx* c, uint32_t* out_handle) {
         dev_free(c->bvh.nodes);
         dev_free(c->bvh.tris);
         dev_free(c->bvh.tri_shade);
+        dev_free(c->bvh.top);
         return fail(c, RT3_E_DEPTH, "LBVH with " + std::to_string(c->bvh.max_depth) + " levels needs " + std::to_string(stack_need) +
                                         " stack entries, the traversal kernels hold " + std::to_string(kMaxStack));
     }
@@ -1419,9 +1421,9 @@ int rt3_trace_rays(rt3_ctx* c, const float* rays, uint32_t n, int any_hit, float
     auto launch = [&]() {
         (void)hipMemsetAsync(d_cur, 0, 4, c->stream);  // ray-pool cursor
         if (any_hit)
-            launch_shadow(c->stream, count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, d_rays, n, nullptr, n, n, nullptr, nullptr, nullptr, 0, d_occ, d_cn, d_ct, nullptr, d_cur);
+            launch_shadow(c->stream, count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->bvh.top, c->bvh.n_top, d_rays, n, nullptr, n, n, nullptr, nullptr, nullptr, 0, d_occ, d_cn, d_ct, nullptr, d_cur);
         else
-            launch_extend(c->stream, count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, d_rays, n, nullptr, n, n, d_hits, d_cn, d_ct, nullptr, d_cur);
+            launch_extend(c->stream, count, c->bvh.layout, c->bvh.nodes, c->bvh.tris, c->bvh.top, c->bvh.n_top, d_rays, n, nullptr, n, n, d_hits, d_cn, d_ct, nullptr, d_cur);
     };
     launch();  // warm-up (also the result-producing launch)
     TR(hipEventRecord(e0, c->stream));

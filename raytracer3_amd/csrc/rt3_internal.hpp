@@ -22,7 +22,8 @@ constexpr int kLayoutWide128 = 1;    // 128 B: four {fp32 min, max, ref, pad} sl
 constexpr int kLayoutWide48Q = 3;    // 48 B: as kLayoutWide64Q, references implied (node_base / tri_base + a nibble per child): 3 loads per node
 constexpr int kC48Stride = 3;        // float4s per compact node
 constexpr int kLayoutWide64Q = 2;    // 64 B: origin + power-of-two steps + four 8-bit boxes + four references
-constexpr uint32_t kMaxStack = 64;         // traversal stack entries: LDS short stack (20) + private spill (44)
+constexpr uint32_t kMaxStack = 64;         // traversal stack entries: LDS short stack (12) + private spill (52)
+constexpr uint32_t kTopCacheNodes = 128;   // top-of-tree nodes the traversal kernels hold in LDS (8 KiB)
 
 struct ShadeLaunch {
     GConstDev g;
@@ -49,13 +50,13 @@ struct ShadeLaunch {
 };
 
 void launch_raygen(hipStream_t st, const GConstDev& g, const uint32_t* pixels, uint32_t npix, float* rays, size_t stride);
-void launch_extend(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float* rays, size_t stride,
+void launch_extend(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float4* top, uint32_t n_top, const float* rays, size_t stride,
                    const uint32_t* count_ptr, uint32_t count_imm, uint32_t max_n, float* hits, uint32_t* cn, uint32_t* ct,
                    unsigned long long* totals, uint32_t* work_counter, bool payload = false);
-void launch_shadow(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float* rays, size_t stride,
+void launch_shadow(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float4* top, uint32_t n_top, const float* rays, size_t stride,
                    const uint32_t* count_ptr, uint32_t count_imm, uint32_t max_n, const float* contrib, const uint32_t* pid, float* lacc,
                    size_t lstride, uint32_t* occluded_out, uint32_t* cn, uint32_t* ct, unsigned long long* totals, uint32_t* work_counter);
-void launch_trace(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float* ext_rays, const float* sh_rays,
+void launch_trace(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float4* top, uint32_t n_top, const float* ext_rays, const float* sh_rays,
                   size_t stride, const uint32_t* ext_count, const uint32_t* sh_count, uint32_t max_n, float* hits, const float* contrib, float* lacc,
                   unsigned long long* totals, uint32_t* work_ext, uint32_t* work_sh);
 void launch_gbuffer(hipStream_t st, const SceneDev& sc, const uint32_t* pixels, uint32_t npix, uint32_t width, const float* hits,
@@ -94,6 +95,8 @@ struct LbvhResult {
     int layout = kLayoutWide128;
     float4* tris = nullptr;    // n_tris x 3 float4 (48 B), Morton order
     float4* tri_shade = nullptr;  // n_tris x 4 float4 (64 B), global primitive order: vertex normals + geometry index
+    float4* top = nullptr;     // quantised four-wide layout: the first n_top nodes in breadth-first order (64 B each), child references to
+    uint32_t n_top = 0;        // cached nodes rewritten as 0x40000000 | slot -- the traversal kernels keep this copy in LDS
     uint32_t n_nodes = 0, n_tris = 0, max_depth = 0;
 };
 hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,

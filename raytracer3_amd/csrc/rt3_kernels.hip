@@ -19,7 +19,14 @@ namespace rt3 {
 // ------------------------------------------------------------------------------------------------ traversal
 // One ray per lane.  Short stack: kLdsStack entries per lane in LDS ([entry][lane] so a wave's ds_read_b32 /
 // ds_write_b32 hit 64 consecutive dwords: conflict-free), deeper entries spill to a private array (scratch).
-constexpr int kLdsStack = 20;  // 20 KiB per 256-thread block -> 8 blocks = 8 waves per SIMD in 160 KiB (24 entries: 6 waves, 4 % slower; 16: more spills)
+// LDS per 256-thread block: 12 KiB of stack + 8 KiB of cached top-of-tree nodes = 20 KiB -> 8 blocks = 8 waves per SIMD in 160 KiB.
+// Stack: a diffuse ray's stack is 4 entries deep at the median, 6 at the 90th and 9 at the 99th percentile (13 at most on the atrium).
+constexpr int kLdsStack = 12;
+// Top-of-tree cache (quantised four-wide layout): the first kTopNodes nodes of the tree in breadth-first order live in LDS, copied at
+// kernel start from a 8 KiB array the builder prepares (k_top_cache).  They receive 46 % of all node visits (the root alone 5 %), and the
+// walk is bound by the rate at which the vector-memory path returns gathered bytes (profiles/r02_gather_cap.md): these visits now go
+// through the LDS instead.  In the cached copies a reference to a child that is itself cached is kTopFlag | slot.
+constexpr uint32_t kTopFlag = 0x40000000u;
 constexpr int kSpill = 64 - kLdsStack;  // kLdsStack + kSpill >= kMaxBvhDepth (checked on the host after the build)
 constexpr uint32_t kMaxSteps = 1u << 20;  // safety bound on traversal steps per ray (a corrupt tree must not hang the GPU)
 
@@ -86,6 +93,15 @@ void set_pool_chunk(uint32_t v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pool_chun
 static unsigned g_trace_max_blocks = kExtendMaxBlocks;  // persistent traversal workgroups per launch (RT3_OPT_TRACE_BLOCKS)
 void set_trace_blocks(uint32_t v) { g_trace_max_blocks = v; }
 
+constexpr uint32_t kTopNodes = 128;  // 8 KiB
+// copies the builder's top-of-tree array into LDS (kernel-uniform: either every thread of every block does, or none)
+__device__ __forceinline__ bool load_top(float4* s_top, const float4* __restrict__ top, uint32_t n_top) {
+    if (top == nullptr || n_top == 0u) return false;
+    for (uint32_t i = threadIdx.x; i < 4u * n_top; i += kExtendBlock) s_top[i] = top[i];
+    __syncthreads();
+    return true;
+}
+
 struct LaneRay {  // traversal state of the ray a lane currently owns
     V3 o, d, inv;
     float tmin, inv_dd;  // inv_dd = 1 / d.d (the triangle test makes no unit-length assumption)
@@ -103,7 +119,7 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
                                              const float* __restrict__ rays_a, size_t stride, uint32_t n_a, uint32_t* __restrict__ work_counter_a,
                                              uint32_t* __restrict__ lds, Finish finish, bool any_payload = false,
                                              const float* __restrict__ rays_b = nullptr, uint32_t n_b = 0, uint32_t* __restrict__ work_counter_b = nullptr,
-                                             bool ext_payload = false) {
+                                             bool ext_payload = false, const float4* top_lds = nullptr, bool use_top = false) {
     // any_payload: the any-hit rays come from k_shade's shadow queue, where every ray has the range (kRayTMin, kBackgroundDepth):
     // the two .w slots of its record carry payload (two contribution channels) instead of tmin / tmax -- 16 bytes less per ray.
     // ext_payload: likewise for the extension rays of the path tracer's own queue (.w = the path's pdf and id, read by k_shade)
@@ -180,7 +196,7 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
                 r.pay1 = rd.w;
                 r.inv = v3(guarded_inverse(r.d.x), guarded_inverse(r.d.y), guarded_inverse(r.d.z));
                 r.inv_dd = 1.0f / dot_fma(r.d, r.d);
-                r.cur = 0u;
+                r.cur = (LAYOUT == kLayoutWide64Q && use_top) ? kTopFlag : 0u;  // the root: slot 0 of the LDS copy, or node 0
                 r.leaf_k = 0u;
                 r.sp = 0;
                 r.index = idx;
@@ -210,9 +226,22 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
         const bool ANY = MODE == 2 ? lane_any : MODE == 1;  // compile-time constant for MODE 0 / 1, per lane for MODE 2
         const bool is_leaf = (r.cur & 0x80000000u) != 0u;
         const uint32_t first = r.cur & 0x0FFFFFFFu, cnt = ((r.cur >> 28) & 7u) + 1u;
-        const float4* p = is_leaf ? tris + 3 * (size_t)(first + r.leaf_k) : nodes + (WIDE ? 8 : (C48 ? kC48Stride : 4)) * (size_t)r.cur;
+        const bool cached = LAYOUT == kLayoutWide64Q && !is_leaf && (r.cur & kTopFlag) != 0u;  // a top-of-tree node held in LDS
+        const float4* p = is_leaf ? tris + 3 * (size_t)(first + r.leaf_k) : nodes + (WIDE ? 8 : (C48 ? kC48Stride : 4)) * (size_t)(cached ? 0u : r.cur);
         // one batch of loads (the triangle array carries 128 B of slack so that over-reading a leaf is in bounds)
-        float4 q0 = p[0], q1 = p[1], q2 = p[2], q3 = C48 ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : p[3], q4, q5, q6, q7;
+        float4 q0, q1, q2, q3, q4, q5, q6, q7;
+        if (LAYOUT == kLayoutWide64Q && cached) {
+            const float4* t = top_lds + 4 * (r.cur & 0xFFFFu);
+            q0 = t[0];
+            q1 = t[1];
+            q2 = t[2];
+            q3 = t[3];
+        } else {
+            q0 = p[0];
+            q1 = p[1];
+            q2 = p[2];
+            q3 = C48 ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : p[3];
+        }
         if (WIDE) {
             q4 = p[4];
             q5 = p[5];
@@ -375,13 +404,15 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
 // closest-hit over a ray queue.  rays: two float4 streams of `stride` records, {o.xyz, tmin} then {d.xyz, tmax};
 // hits: one float4 {t, u, v, prim} per ray.  16-byte records are the widest coalesced access (1 KiB per wave instruction).
 template <bool COUNT, int LAYOUT>
-__global__ __launch_bounds__(kExtendBlock) void k_extend(const float4* __restrict__ nodes, const float4* __restrict__ tris,
+__global__ __launch_bounds__(kExtendBlock) void k_extend(const float4* __restrict__ nodes, const float4* __restrict__ tris, const float4* __restrict__ top, uint32_t n_top,
                                                          const float* __restrict__ rays, size_t stride,
                                                          const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
                                                          float* __restrict__ hits, uint32_t* __restrict__ cnt_nodes,
                                                          uint32_t* __restrict__ cnt_tris, unsigned long long* __restrict__ totals,
                                                          uint32_t* __restrict__ work_counter, int payload) {
     __shared__ uint32_t stack[kLdsStack * kExtendBlock];
+    __shared__ float4 s_top[4 * kTopNodes];
+    const bool use_top = load_top(s_top, top, n_top);  // (the LDS array itself is passed on, never a selected pointer: a select would turn its reads into flat loads)
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
     unsigned long long tot_n = 0, tot_t = 0;
     auto finish = [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, bool, float, float) {
@@ -395,7 +426,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(const float4* __restric
             tot_t += ct;
         }
     };
-    trace_stream<0, COUNT, LAYOUT>(nodes, tris, rays, stride, n, work_counter, stack + threadIdx.x, finish, false, nullptr, 0, nullptr, payload != 0);
+    trace_stream<0, COUNT, LAYOUT>(nodes, tris, rays, stride, n, work_counter, stack + threadIdx.x, finish, false, nullptr, 0, nullptr, payload != 0, s_top, use_top);
     if (COUNT && totals) {
         atomicAdd(&totals[0], tot_n);
         atomicAdd(&totals[1], tot_t);
@@ -405,7 +436,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(const float4* __restric
 // any-hit over the shadow queue; unoccluded rays add their contribution to the path's radiance slot.
 // If `occluded_out` != nullptr the kernel only reports occlusion (rt3_trace_rays).
 template <bool COUNT, int LAYOUT>
-__global__ __launch_bounds__(kExtendBlock) void k_shadow(const float4* __restrict__ nodes, const float4* __restrict__ tris,
+__global__ __launch_bounds__(kExtendBlock) void k_shadow(const float4* __restrict__ nodes, const float4* __restrict__ tris, const float4* __restrict__ top, uint32_t n_top,
                                                          const float* __restrict__ rays, size_t stride,
                                                          const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
                                                          const float* __restrict__ contrib, const uint32_t* __restrict__ pid,
@@ -414,6 +445,8 @@ __global__ __launch_bounds__(kExtendBlock) void k_shadow(const float4* __restric
                                                          uint32_t* __restrict__ cnt_tris, unsigned long long* __restrict__ totals,
                                                          uint32_t* __restrict__ work_counter) {
     __shared__ uint32_t stack[kLdsStack * kExtendBlock];
+    __shared__ float4 s_top[4 * kTopNodes];
+    const bool use_top = load_top(s_top, top, n_top);  // (the LDS array itself is passed on, never a selected pointer: a select would turn its reads into flat loads)
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
     unsigned long long tot_n = 0, tot_t = 0;
     trace_stream<1, COUNT, LAYOUT>(
@@ -434,7 +467,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_shadow(const float4* __restric
                 tot_t += ct;
             }
         },
-        occluded_out == nullptr);
+        occluded_out == nullptr, nullptr, 0, nullptr, false, s_top, use_top);
     if (COUNT && totals) {
         atomicAdd(&totals[0], tot_n);
         atomicAdd(&totals[1], tot_t);
@@ -446,13 +479,15 @@ __global__ __launch_bounds__(kExtendBlock) void k_shadow(const float4* __restric
 // waves finish (each k_extend / k_shadow pair cost one such drain more), which matters most when the frame is split
 // over several GPUs and every launch is 1/N as long.  totals (counting mode): {rays, nodes, tris} x {closest, any}.
 template <bool COUNT, int LAYOUT>
-__global__ __launch_bounds__(kExtendBlock) void k_trace(const float4* __restrict__ nodes, const float4* __restrict__ tris,
+__global__ __launch_bounds__(kExtendBlock) void k_trace(const float4* __restrict__ nodes, const float4* __restrict__ tris, const float4* __restrict__ top, uint32_t n_top,
                                                         const float* __restrict__ ext_rays, const float* __restrict__ sh_rays, size_t stride,
                                                         const uint32_t* __restrict__ ext_count, const uint32_t* __restrict__ sh_count,
                                                         float* __restrict__ hits, const float* __restrict__ contrib, float* __restrict__ lacc,
                                                         unsigned long long* __restrict__ totals, uint32_t* __restrict__ work_ext,
                                                         uint32_t* __restrict__ work_sh) {
     __shared__ uint32_t stack[kLdsStack * kExtendBlock];
+    __shared__ float4 s_top[4 * kTopNodes];
+    const bool use_top = load_top(s_top, top, n_top);  // (the LDS array itself is passed on, never a selected pointer: a select would turn its reads into flat loads)
     const uint32_t n_ext = *ext_count, n_sh = *sh_count;
     unsigned long long en = 0, et = 0, sn = 0, stt = 0;
     trace_stream<2, COUNT, LAYOUT>(
@@ -473,7 +508,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_trace(const float4* __restrict
                 stt += any ? ct : 0u;
             }
         },
-        true, sh_rays, n_sh, work_sh, true);
+        true, sh_rays, n_sh, work_sh, true, s_top, use_top);
     if (COUNT && totals) {
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             atomicAdd(&totals[0], (unsigned long long)n_ext);
@@ -992,12 +1027,12 @@ static inline unsigned grid_for(uint64_t n, unsigned block, unsigned max_blocks)
 void launch_raygen(hipStream_t st, const GConstDev& g, const uint32_t* pixels, uint32_t npix, float* rays, size_t stride) {
     hipLaunchKernelGGL(k_raygen, dim3(grid_for(npix, 256, 4096)), dim3(256), 0, st, g, pixels, npix, rays, stride);
 }
-void launch_extend(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float* rays, size_t stride,
+void launch_extend(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float4* top, uint32_t n_top, const float* rays, size_t stride,
                    const uint32_t* count_ptr, uint32_t count_imm, uint32_t max_n, float* hits, uint32_t* cn, uint32_t* ct,
                    unsigned long long* totals, uint32_t* work_counter, bool payload) {
     unsigned grid = grid_for(max_n, kExtendBlock, g_trace_max_blocks);
 #define RT3_LAUNCH_EXTEND(C, L)                                                                                                                  \
-    hipLaunchKernelGGL((k_extend<C, L>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, hits, cn, ct, totals, \
+    hipLaunchKernelGGL((k_extend<C, L>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, top, n_top, rays, stride, count_ptr, count_imm, hits, cn, ct, totals, \
                        work_counter, payload ? 1 : 0)
     if (count) {
         if (layout == kLayoutWide48Q) RT3_LAUNCH_EXTEND(true, kLayoutWide48Q);
@@ -1012,12 +1047,12 @@ void launch_extend(hipStream_t st, bool count, int layout, const float4* nodes, 
     }
 #undef RT3_LAUNCH_EXTEND
 }
-void launch_shadow(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float* rays, size_t stride,
+void launch_shadow(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float4* top, uint32_t n_top, const float* rays, size_t stride,
                    const uint32_t* count_ptr, uint32_t count_imm, uint32_t max_n, const float* contrib, const uint32_t* pid, float* lacc,
                    size_t lstride, uint32_t* occluded_out, uint32_t* cn, uint32_t* ct, unsigned long long* totals, uint32_t* work_counter) {
     unsigned grid = grid_for(max_n, kExtendBlock, g_trace_max_blocks);
 #define RT3_LAUNCH_SHADOW(C, L)                                                                                                                \
-    hipLaunchKernelGGL((k_shadow<C, L>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, rays, stride, count_ptr, count_imm, contrib, pid, lacc, \
+    hipLaunchKernelGGL((k_shadow<C, L>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, top, n_top, rays, stride, count_ptr, count_imm, contrib, pid, lacc, \
                        lstride, occluded_out, cn, ct, totals, work_counter)
     if (count) {
         if (layout == kLayoutWide48Q) RT3_LAUNCH_SHADOW(true, kLayoutWide48Q);
@@ -1032,12 +1067,12 @@ void launch_shadow(hipStream_t st, bool count, int layout, const float4* nodes, 
     }
 #undef RT3_LAUNCH_SHADOW
 }
-void launch_trace(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float* ext_rays, const float* sh_rays,
+void launch_trace(hipStream_t st, bool count, int layout, const float4* nodes, const float4* tris, const float4* top, uint32_t n_top, const float* ext_rays, const float* sh_rays,
                   size_t stride, const uint32_t* ext_count, const uint32_t* sh_count, uint32_t max_n, float* hits, const float* contrib, float* lacc,
                   unsigned long long* totals, uint32_t* work_ext, uint32_t* work_sh) {
     unsigned grid = grid_for(max_n, kExtendBlock, g_trace_max_blocks);
 #define RT3_LAUNCH_TRACE(C, L)                                                                                                                  \
-    hipLaunchKernelGGL((k_trace<C, L>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, ext_rays, sh_rays, stride, ext_count, sh_count, hits, \
+    hipLaunchKernelGGL((k_trace<C, L>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, top, n_top, ext_rays, sh_rays, stride, ext_count, sh_count, hits, \
                        contrib, lacc, totals, work_ext, work_sh)
     if (count) {
         if (layout == kLayoutWide48Q) RT3_LAUNCH_TRACE(true, kLayoutWide48Q);

@@ -526,6 +526,33 @@ __global__ void k_emit_nodes(const uint32_t* left, const uint32_t* right, const 
     }
 }
 
+// Top-of-tree cache for the traversal kernels (quantised 64-byte four-wide layout): the first up-to-kTopCacheNodes nodes in breadth-first
+// order, copied verbatim except that a reference to a child that is itself in the cache becomes 0x40000000 | slot.  Slot 0 = the root.
+// The canonical node array is left alone (it is what the parity tests compare with the oracle); the cache is a pure acceleration of
+// the GPU walk and changes neither hits nor per-ray visit counts.  One thread: 128 nodes.
+__global__ void k_top_cache(const float4* __restrict__ nodes, uint32_t n_nodes, uint32_t* __restrict__ top_words /* 16 per slot */, uint32_t* __restrict__ n_top_out) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    uint32_t queue[kTopCacheNodes];
+    uint32_t head = 0, tail = 0;
+    if (n_nodes) queue[tail++] = 0u;
+    while (head < tail) {
+        const uint32_t node = queue[head];
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(nodes + 4 * (size_t)node);
+        uint32_t* dst = top_words + 16 * (size_t)head;
+        for (int k = 0; k < 16; k++) dst[k] = src[k];
+        for (int k = 0; k < 4; k++) {
+            const uint32_t ref = src[10 + k];
+            if (ref == 0xFFFFFFFFu || (ref & 0x80000000u)) continue;  // empty slot / leaf
+            if (tail < kTopCacheNodes) {
+                dst[10 + k] = 0x40000000u | tail;
+                queue[tail++] = ref;
+            }
+        }
+        head++;
+    }
+    *n_top_out = tail;
+}
+
 // single-triangle scene: root with the leaf in slot 0 and empty other slots
 __global__ void k_single(const float* lmin, const float* lmax, int wide, int quant, float4* nodes) {
     const float inf = INFINITY;
@@ -1794,6 +1821,16 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
         }
         hipLaunchKernelGGL(k_emit_nodes, dim3(grid), dim3(256), 0, st, left, right, rlo, rcnt, keep, newidx, lmin, lmax, nbox, nn, leaf_max, wide,
                            quant, collapse, out->nodes, cbase, tbase, tris_morton, out->tris);
+        if (wide && quant == 1) {  // top-of-tree copy the traversal kernels keep in LDS
+            uint32_t* d_ntop = nullptr;
+            LB_CHECK(hipMalloc(&out->top, (size_t)kTopCacheNodes * 64));
+            LB_CHECK(hipMalloc(&d_ntop, 4));
+            hipLaunchKernelGGL(k_top_cache, dim3(1), dim3(1), 0, st, out->nodes, out->n_nodes, (uint32_t*)out->top, d_ntop);
+            hipError_t e3 = hipMemcpyAsync(&out->n_top, d_ntop, 4, hipMemcpyDeviceToHost, st);
+            if (e3 == hipSuccess) e3 = hipStreamSynchronize(st);
+            (void)hipFree(d_ntop);
+            LB_CHECK(e3);
+        }
         LB_CHECK(hipGetLastError());
         LB_CHECK(hipStreamSynchronize(st));
         if (getenv("RT3_TRACE_BUILD"))
@@ -1809,6 +1846,9 @@ done:
         (void)hipFree(out->nodes);
         (void)hipFree(out->tris);
         (void)hipFree(out->tri_shade);
+        (void)hipFree(out->top);
+        out->top = nullptr;
+        out->n_top = 0;
         out->nodes = nullptr;
         out->tris = nullptr;
         out->tri_shade = nullptr;
