@@ -463,7 +463,7 @@ int pass_reference_mode(rt3_ctx* c, const rt3_gconst* g, uint32_t x, uint32_t y,
         launch_pixbn(c->stream, pl->dev, npix, c->d_bn, c->bn_w, c->bn_h, pl->dev_bn);
         pl->bn_stamp = c->bn_stamp;
     }
-    // paths per wavefront batch: 188 B of queue state each, so 2^28 paths = 50 GB of the 288 GB; the C3 frame (132.7 M paths)
+    // paths per wavefront batch: 160 B of queue state each, so 2^28 paths = 43 GB of the 288 GB; the C3 frame (132.7 M paths)
     // is ONE batch.  Larger launches amortise the ramp / tail of the persistent traversal kernels: 16 -> 64 spp per batch = -6.5 % frame time.
     uint64_t max_paths = 1ull << 28;
     uint32_t sb = c->opt_batch_spp > 0 ? (uint32_t)c->opt_batch_spp : (uint32_t)std::max<uint64_t>(1, max_paths / npix);
