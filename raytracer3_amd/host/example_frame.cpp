@@ -6,11 +6,16 @@
 // With the trailing word `probes` the frame is the probe-GI chain of the old shaders instead (gbuffer ->
 // structured_importance_sampling -> trace_probes -> spherical_harmonic_conversion -> interpolate_probes) and
 // out.bin holds Light followed by the probe atlas.
+// Multi-GPU (one process per GPU, like `bench.py --gpus N`): with RT3_RANKS = n > 0 in the environment this process is rank RT3_RANK of n on
+// device RT3_DEVICE (default: the rank), renders its 64x64 tiles and joins the frame's ONE collective, rt3_gather_tiles; rank 0 creates the
+// RCCL id and hands it to the others through the file RT3_UID_FILE (the C ABI opens no channel of its own) and writes out.bin.
 // scene.bin: u32 n_verts, n_idx, n_geoms, sky_w, sky_h, bn_w, bn_h, pad | verts (n*8 f32) | indices (u32) |
 //            geometry infos (64 B each) | prim counts (u32) | sky rgb f32 | blue noise rgba8 | camera: pos[3] dir[3] fov aspect (f32)
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "render_graph.hpp"
@@ -42,8 +47,30 @@ int main(int argc, char** argv) {
         fclose(f);
         const uint32_t W = atoi(argv[2]), H = atoi(argv[3]);
 
-        rt3::Context ctx(0);
-        ctx.check(rt3_set_tile_partition(ctx.raw(), W, H, 0, 1), "partition");
+        const uint32_t n_ranks = getenv("RT3_RANKS") ? (uint32_t)atoi(getenv("RT3_RANKS")) : 0u;  // 0: single process, no communicator
+        const uint32_t rank = n_ranks && getenv("RT3_RANK") ? (uint32_t)atoi(getenv("RT3_RANK")) : 0u;
+        rt3::Context ctx(n_ranks ? (getenv("RT3_DEVICE") ? atoi(getenv("RT3_DEVICE")) : (int)rank) : 0);
+        ctx.check(rt3_set_tile_partition(ctx.raw(), W, H, rank, n_ranks ? n_ranks : 1u), "partition");
+        if (n_ranks) {  // rank 0's id travels over whatever channel the host has -- here a file
+            if (probes) throw std::runtime_error("the probe-GI passes are not tile-partitioned");
+            const char* uid_file = getenv("RT3_UID_FILE");
+            if (!uid_file) throw std::runtime_error("RT3_UID_FILE is not set");
+            unsigned char id[RT3_COMM_ID_BYTES];
+            if (rank == 0) {
+                if (rt3_comm_unique_id(id)) throw std::runtime_error(std::string("rt3_comm_unique_id: ") + rt3_last_error(nullptr));
+                const std::string tmp = std::string(uid_file) + ".tmp";
+                FILE* u = fopen(tmp.c_str(), "wb");
+                if (!u || fwrite(id, 1, sizeof(id), u) != sizeof(id)) throw std::runtime_error("cannot write the id file");
+                fclose(u);
+                if (rename(tmp.c_str(), uid_file)) throw std::runtime_error("cannot publish the id file");
+            } else {
+                FILE* u = nullptr;
+                for (int tries = 0; tries < 1200 && !(u = fopen(uid_file, "rb")); tries++) std::this_thread::sleep_for(std::chrono::milliseconds(50));
+                if (!u || fread(id, 1, sizeof(id), u) != sizeof(id)) throw std::runtime_error("cannot read the id file");
+                fclose(u);
+            }
+            ctx.check(rt3_comm_init(ctx.raw(), id, rank, n_ranks), "comm init");  // collective: ncclCommInitRank on this context's device
+        }
         ctx.check(rt3_scene_set_vertices(ctx.raw(), verts.data(), hdr[0]), "vertices");  // DynamicBuffer::push x3, world/mod.rs:83-101
         ctx.check(rt3_scene_set_indices(ctx.raw(), idx.data(), hdr[1]), "indices");
         ctx.check(rt3_scene_set_geometry(ctx.raw(), geoms.data(), counts.data(), hdr[2]), "geometry");
@@ -115,6 +142,15 @@ int main(int argc, char** argv) {
         rt3::ComputePass::New(rg, "postprocess").shader("postprocess").constants(gconst)
             .read(gb, depth).write(rt3::IMPORTED, color).read(pt, light).dispatch(rt3::DispatchSize::FullScreen());
         rg.draw_frame(color);
+        if (n_ranks) {  // the frame's collective(s): enqueued behind the passes on the context's stream, no host synchronisation
+            ctx.check(rt3_gather_tiles(ctx.raw(), light, 0), "gather Light");
+            ctx.check(rt3_gather_tiles(ctx.raw(), color, 0), "gather color");
+            if (rank != 0) {
+                ctx.check(rt3_frame_wait(ctx.raw()), "wait");
+                printf("example_frame: rank %u of %u sent its tiles\n", rank, n_ranks);
+                return 0;
+            }
+        }
 
         std::vector<float> out((size_t)W * H * 4), col((size_t)W * H * 4);
         ctx.check(rt3_resource_download(ctx.raw(), light, out.data(), out.size() * 4), "download");

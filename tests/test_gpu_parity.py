@@ -5,6 +5,7 @@ expected bit-exact too (arithmetic contract) and must at least meet t
 the display transform (log2/pow from libm vs device) is compared with tolerance 2e-5."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
@@ -531,6 +532,13 @@ def test_cpp_host_renders_the_same_frame(small, tmp_path):
     olight, _ = osc.reference_mode(og, ogb, odepth)
     assert np.array_equal(data[0].view(np.uint32), olight.view(np.uint32))
     assert np.allclose(data[1], osc.postprocess(og, odepth, olight), atol=2e-5, rtol=1e-4)
+    # the same host as one rank of a multi-GPU frame (RT3_RANKS): tile partition, RCCL communicator from an id carried over a file,
+    # rt3_gather_tiles at frame end -- with one rank (all a one-GPU box allows) the gathered frame is the same frame
+    out1 = tmp_path / "out_rank.bin"
+    env = dict(os.environ, RT3_RANKS="1", RT3_RANK="0", RT3_UID_FILE=str(tmp_path / "uid.bin"))
+    subprocess.check_call([str(exe), str(scene), str(W), str(H), str(spp), str(bounces), str(SPEC), str(frame), str(out1)], env=env)
+    assert (tmp_path / "uid.bin").stat().st_size == L.COMM_ID_BYTES
+    assert np.array_equal(np.fromfile(out1, "<f4").view(np.uint32), data.ravel().view(np.uint32))
 
 
 def test_native_asset_pipeline_renders_the_oracle_frame(tmp_path):
