@@ -909,6 +909,35 @@ def test_config_c5_progressive_accumulation_is_a_running_mean():
     assert np.allclose(acc, want, rtol=2e-6, atol=1e-7) and np.abs(acc - np.mean(singles, 0)).max() < 1e-3 * max(1.0, float(acc.max()))
 
 
+def test_progressive_restart_from_a_dumped_accumulation_buffer(small):
+    """SURVEY 5 (checkpoint / resume) for BASELINE configs[4]: the accumulation buffer after pass k plus the pass counter are the whole
+    state of a progressive render -- a fresh context loaded with that buffer as PrevLight reproduces the remaining passes bit for bit
+    (tools/convergence.py does this at 4K; here a small window, Light / PrevLight trading names between passes)."""
+    mesh, sky, bn, _ = small
+    W, H, spp, passes, k = 128, 72, 4, 6, 3
+    cam = Camera(scenes.ATRIUM_CAMERA["position"], scenes.ATRIUM_CAMERA["direction"], math.radians(65.0), W / H)
+
+    def run(first, last, start=None):
+        pt = PathTracer((W, H))
+        pt.set_scene(mesh, sky, bn)
+        if start is not None:
+            pt.load_prev(start)
+        dump = None
+        for p in range(first, last):
+            pt.render(pt.make_gconst(cam, spp, 3, frame=p, blendfactor=1.0 / (p + 1), flags=SPEC), wait=False)
+            if p + 1 == k:
+                dump = pt.light()
+            if p != last - 1:
+                pt.swap_light_prev()
+        img = pt.light()
+        pt.close()
+        return img, dump
+
+    full, dump = run(0, passes)
+    resumed, _ = run(k, passes, start=dump)
+    assert dump is not None and np.array_equal(resumed.view(np.uint32), full.view(np.uint32)) and full[..., :3].mean() > 0
+
+
 def test_non_finite_rays_and_a_nan_camera(cornell):
     """Non-finite rays miss at once on both sides of the ABI; a frame whose camera matrix holds a NaN therefore comes back
     promptly with every pixel on the background instead of walking the whole tree two million times."""
