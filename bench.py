@@ -229,8 +229,26 @@ def main():
         uid = bytes(store.get("rt3_comm_unique_id"))
         if len(uid) != L.COMM_ID_BYTES:
             raise SystemExit(f"bench.py: rank {rank} received a {len(uid)}-byte communicator id")
-        if backend == "nccl":
-            pt.init_comm(uid)
+        gather_mode = "REHEARSAL: host-moved bytes (gloo), ranks share GPUs"
+        if backend == "nccl" or os.environ.get("RT3_TRY_RCCL"):  # (RT3_TRY_RCCL: exercise this block in the one-GPU rehearsal, where RCCL must refuse)
+            # rt3_comm_init has never met more than one GPU before the driver's node: if it fails on ANY rank, every rank
+            # drops to the host-moved exchange over a gloo group, and the JSON line says so -- a labelled fallback instead of no number
+            try:
+                pt.init_comm(uid)
+                ok, why = 1, ""
+            except L.Rt3Error as e:
+                ok, why = 0, str(e)
+                print(f"bench.py: rank {rank}: rt3_comm_init failed: {why}", file=sys.stderr)
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                gather_mode = "rt3_gather_tiles (RCCL)"
+            else:
+                if pt.comm_ready:
+                    pt.ctx.comm_destroy()
+                    pt.comm_ready = False
+                pt.host_group = dist.new_group(backend="gloo")
+                gather_mode = "FALLBACK: rt3_comm_init failed on at least one rank; bytes moved through host tensors (gloo)"
     if args.batch_spp:
         pt.ctx.set_option(L.OPT_BATCH_SPP, args.batch_spp)
     cam = Camera(scenes.ATRIUM_CAMERA["position"], scenes.ATRIUM_CAMERA["direction"], math.radians(scenes.ATRIUM_CAMERA["fov_deg"]), W / H)
@@ -396,7 +414,7 @@ def main():
         "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"C3: atrium stand-in ({mesh.n_triangles} tris) {W}x{H}@{args.spp}spp B={args.bounces} layered BSDF (diffuse + GGX) + sky NEE/MIS + bluenoise, "
-                               f"64x64 tiles over {world} GPU(s), one gather", "rays_per_frame": int(rays_total / max(args.steps, 1)), "gather": ("none" if world == 1 else ("rt3_gather_tiles (RCCL)" if backend == "nccl" else "REHEARSAL: host-moved bytes (gloo), ranks share GPUs")),
+                               f"64x64 tiles over {world} GPU(s), one gather", "rays_per_frame": int(rays_total / max(args.steps, 1)), "gather": ("none" if world == 1 else gather_mode),
                    "extension_rays_per_frame": int(ext_total / max(args.steps, 1)), "shadow_rays_per_frame": int(sh_total / max(args.steps, 1)),
                    "device": pt.ctx.device_name},
         "roofline": roofline,

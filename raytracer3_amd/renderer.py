@@ -57,6 +57,7 @@ class PathTracer:
         self._accel = None
         self.comm_ready = False  # True once init_comm() has joined librt3's RCCL communicator
         self._stage = None       # rehearsal path only: staging buffer of the host-moved gather
+        self.host_group = None   # process group of the host-moved gather (None = the default group)
 
     def close(self):
         self.ctx.close()
@@ -202,7 +203,7 @@ class PathTracer:
                     ptr, _ = self.rg.device_ptr(self._stage)
                     self.ctx.check(self.ctx.lib.rt3_image_pack_tiles(self.ctx.h, img, self.rank, self.n_ranks, C.c_void_p(ptr)))
                     mine = self.rg.download(self._stage, (max(n, 1), 4), np.float32)[:n]
-                recv = exchange_tiles_host(dist, torch, self.rank, self.n_ranks, off, mine, dst)
+                recv = exchange_tiles_host(dist, torch, self.rank, self.n_ranks, off, mine, dst, group=self.host_group)
                 if self.rank == dst and off[-1]:
                     if self._stage is None:
                         self._stage = self.rg.buffer(off[-1] * 16, "gather_stage")
@@ -222,16 +223,16 @@ def gather_offsets(counts, root):
     return off
 
 
-def exchange_tiles_host(dist, torch, rank, n_ranks, offsets, mine, dst=0):
+def exchange_tiles_host(dist, torch, rank, n_ranks, offsets, mine, dst=0, group=None):
     """Host-memory stand-in for the RCCL exchange inside `rt3_gather_tiles` (gloo: CPU tests, one-GPU rehearsal): every rank
     but `dst` sends its packed tiles (n x 4 float32) point to point; `dst` receives rank r's at offsets[r]..offsets[r+1] of ONE
     contiguous buffer, all receives posted together.  Returns that buffer on `dst`, None elsewhere."""
     if rank != dst:
         if mine is not None and len(mine):
-            dist.send(torch.from_numpy(np.ascontiguousarray(mine, np.float32)), dst)
+            dist.send(torch.from_numpy(np.ascontiguousarray(mine, np.float32)), dst, group=group)
         return None
     recv = torch.empty((offsets[-1], 4), dtype=torch.float32)
-    reqs = [dist.irecv(recv[offsets[r]:offsets[r + 1]], src=r) for r in range(n_ranks) if r != dst and offsets[r + 1] > offsets[r]]
+    reqs = [dist.irecv(recv[offsets[r]:offsets[r + 1]], src=r, group=group) for r in range(n_ranks) if r != dst and offsets[r + 1] > offsets[r]]
     for q in reqs:
         q.wait()
     return recv.numpy()

@@ -674,6 +674,27 @@ def test_multi_rank_gather_rehearsal(tmp_path):
     assert "REHEARSAL" in d["config"]["gather"]
 
 
+def test_bench_falls_back_when_the_communicator_cannot_be_built():
+    """The RCCL communicator has never met more than one GPU before the driver's node.  If rt3_comm_init fails on any rank, every rank
+    of bench.py must drop to the host-moved exchange and SAY SO on the JSON line, rather than die without a number.  Provoked for real
+    here: two self-launched ranks share GPU 0 (gloo rehearsal) and are told to try RCCL, which refuses the duplicate device."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RT3_DIST_BACKEND="gloo", RT3_TRY_RCCL="1", RT3_CHECK_GATHER="1")
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu", "--width", "200", "--height", "150", "--spp", "2", "--detail", "0.3"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=500)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["gather"].startswith("FALLBACK") and d["gather_bit_identical_to_single_rank"] is True
+    assert "rt3_comm_init failed" in r.stderr
+
+
 def test_bench_refuses_more_ranks_than_devices():
     """The same command on the real backend (RCCL cannot put two ranks on one GPU): with fewer than N visible devices it must exit
     non-zero with a message, never report a 1-GPU number as the N-GPU point."""
