@@ -374,13 +374,15 @@ def main():
         if shade_ms > 0 and abs(prof_shade_ms / shade_ms - 1.0) <= 0.05:
             shade_traffic = sh_first["hbm_bytes_per_launch"] + sh_later["hbm_bytes_per_launch"] * (args.bounces - 1)
     roofline = {
-        "kernel": dom_name, "bound": "hbm", "peak": peak, "unit": "GB/s",
+        # NOT bound by HBM (achieved / peak / frac below are its measured HBM-side share, 0.3): the walk is bound by the rate at which the
+        # memory system returns L1-missing random lines of a cache-resident 17 MB tree and by VALU issue -- see `binding`, `algorithmic`
+        "kernel": dom_name, "bound": "gather-rate + valu-issue (hbm share in frac)", "peak": peak, "unit": "GB/s",
         # measured HBM-side (fabric) bytes of one launch / its live duration: the fraction of the HBM roofline the kernel occupies
         "achieved": ke["achieved"] if ke["achieved"] is not None else round(stream_gbps, 1),
         "frac": ke["frac"] if ke["frac"] is not None else round(stream_gbps / peak, 4),
         "achieved_is": ("counter traffic (2 x FETCH_SIZE for 16 B/lane streaming reads, validated for 64 B gathers by profiles/r02_fetch_calibration.md) / live launch time"
                         if ke["achieved"] is not None else "LOWER BOUND: compulsory queue bytes only (48 B per ray); no current counter profile for this workload"),
-        "traffic": ke["traffic"], "traffic_uncorrected": ke["traffic_raw"], "traffic_source": prof["_file"] if (prof and ke["traffic"] is not None) else None,
+        "hbm_side_frac": ke["frac"], "traffic": ke["traffic"], "traffic_uncorrected": ke["traffic_raw"], "traffic_source": prof["_file"] if (prof and ke["traffic"] is not None) else None,
         "compulsory_stream": {"bytes_per_launch": round(stream_bytes), "GBps": round(stream_gbps, 1), "frac": round(stream_gbps / peak, 4)},
         # SURVEY 8d's contract figure.  NOT an HBM fraction: the 17 MB BVH is L2 / Infinity-Cache resident, so these bytes are cache-side
         # gathers; the comparable ceilings are the measured gather rates (MI355X_MICROARCH.md: 8.6 TB/s from the Infinity Cache,
