@@ -87,6 +87,7 @@ struct rt3_ctx {
     float* d_srgb_lut = nullptr;
     bool tex_dirty = false;
     LbvhResult bvh;
+    BuildArena build_arena;
     bool accel_built = false;
     std::vector<uint32_t> h_indices;  // host copies, only for range validation (rt3_scene_set_geometry, again in rt3_accel_build)
     std::vector<rt3_geometry_info> h_geoms;
@@ -692,6 +693,7 @@ void rt3_destroy(rt3_ctx* c) {
     dev_free(c->d_tex_pixels); dev_free(c->d_tex_table); dev_free(c->d_srgb_lut);
     dev_free(c->d_sky); dev_free(c->d_sky_alias); dev_free(c->d_cdf_marg); dev_free(c->d_bn);
     dev_free(c->bvh.nodes); dev_free(c->bvh.tris); dev_free(c->bvh.tri_shade); dev_free(c->bvh.top); dev_free(c->d_guide_marg);
+    c->build_arena.release();
     for (auto& r : c->resources)
         if (r.owned && r.ptr) (void)hipFree(r.ptr);
     for (auto& p : c->pixlists) {
@@ -1039,7 +1041,8 @@ int rt3_accel_build(rt3_ctx* c, uint32_t* out_handle) {
     dev_free(c->bvh.tri_shade);
     dev_free(c->bvh.top);
     hipError_t e = lbvh_build(c->stream, c->d_verts, c->d_indices, c->d_geoms, c->d_prim_geom, c->d_first_prim, c->n_prims, c->opt_leaf_size,
-                              c->opt_node_width, c->opt_node_quant, c->opt_collapse, c->opt_sah_top, c->opt_sah_device, &c->bvh);
+                              c->opt_node_width, c->opt_node_quant, c->opt_collapse, c->opt_sah_top, c->opt_sah_device, c->build_arena, &c->bvh);
+    if (c->build_arena.cap > ((size_t)1 << 30)) c->build_arena.release();  // a big scene's scratch is not worth keeping resident
     if (e != hipSuccess) return fail(c, RT3_E_HIP, std::string("lbvh_build: ") + hipGetErrorString(e));
     // worst-case stack use of the near-first walk: (children per node - 1) entries per level above the leaves
     const uint32_t stack_need = c->bvh.max_depth > 1 ? (c->opt_node_width - 1) * (c->bvh.max_depth - 1) : 0;

@@ -89,6 +89,35 @@ void launch_selftest(hipStream_t st, int op, const uint32_t* in, uint32_t n, uin
 
 // LBVH build (rt3_lbvh.hip).  All pointers are device memory owned by the caller except the scratch the builder
 // allocates and frees itself.  Returns hipSuccess or the failing HIP error; *max_depth is read back to the host.
+// Scratch memory of the builder: ONE device allocation, handed out by a bump pointer and kept by the context from build to build
+// (a build made ~50 hipMalloc / hipFree pairs before, a third of its wall time on a 260 k-triangle scene).
+struct BuildArena {
+    char* base = nullptr;
+    size_t cap = 0, used = 0;
+    hipError_t reserve(size_t bytes) {  // a fresh build: everything handed out before is void
+        used = 0;
+        if (bytes <= cap) return hipSuccess;
+        if (base) (void)hipFree(base);
+        base = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc((void**)&base, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    template <typename T>
+    hipError_t take(T** p, size_t bytes) {
+        const size_t at = (used + 255) & ~(size_t)255;
+        if (at + bytes > cap) return hipErrorOutOfMemory;  // the builder's bound on its own scratch was wrong: fail, never overrun
+        *p = reinterpret_cast<T*>(base + at);
+        used = at + bytes;
+        return hipSuccess;
+    }
+    void release() {
+        if (base) (void)hipFree(base);
+        base = nullptr;
+        cap = used = 0;
+    }
+};
 struct LbvhResult {
     float4* nodes = nullptr;   // n_nodes x node_bytes: 64 B {box0, box1, ref0, ref1, pad} or 128 B 4 x {min, max, ref, pad}
     uint32_t node_bytes = 128;
@@ -101,6 +130,6 @@ struct LbvhResult {
 };
 hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,
                       const uint32_t* first_prim, uint32_t n_prims, uint32_t leaf_max, uint32_t node_width, uint32_t node_quant, uint32_t collapse_mode,
-                      uint32_t sah_top, uint32_t sah_device, LbvhResult* out);
+                      uint32_t sah_top, uint32_t sah_device, BuildArena& arena, LbvhResult* out);
 
 }  // namespace rt3

@@ -79,14 +79,24 @@ __global__ void k_prim_bounds(const float* verts, const uint32_t* indices, const
             chi[k] = fmax_sel(chi[k], __shfl_xor(chi[k], off));
         }
     }
+    // one set of 12 atomics per workgroup, and few workgroups (the launch caps the grid): the 12 words share a cache line, on which
+    // returning or not, atomics retire at ~90 per microsecond -- 48 k of them (one set per wave of a full grid) took 0.55 ms
+    __shared__ uint32_t s_b[12];
+    if (threadIdx.x < 12) s_b[threadIdx.x] = (threadIdx.x % 6) < 3 ? 0xFFFFFFFFu : 0u;
+    __syncthreads();
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
         for (int k = 0; k < 3; k++) {
-            atomicMin(&bounds[k], float_to_ordered(lo[k]));
-            atomicMax(&bounds[3 + k], float_to_ordered(hi[k]));
-            atomicMin(&bounds[6 + k], float_to_ordered(clo[k]));
-            atomicMax(&bounds[9 + k], float_to_ordered(chi[k]));
+            atomicMin(&s_b[k], float_to_ordered(lo[k]));
+            atomicMax(&s_b[3 + k], float_to_ordered(hi[k]));
+            atomicMin(&s_b[6 + k], float_to_ordered(clo[k]));
+            atomicMax(&s_b[9 + k], float_to_ordered(chi[k]));
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        if ((threadIdx.x % 6) < 3) atomicMin(&bounds[threadIdx.x], s_b[threadIdx.x]);
+        else atomicMax(&bounds[threadIdx.x], s_b[threadIdx.x]);
     }
 }
 
@@ -245,6 +255,29 @@ __global__ void k_refit(const uint32_t* left, const uint32_t* right, const uint3
                 __hip_atomic_store(&nbox[6 * (size_t)cur + 3 + j], fmax_sel(mx[0][j], mx[1][j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             cur = parent_internal[cur];
+        }
+    }
+}
+
+// The boxes of the nodes at and below the cluster roots of the SAH top (subtrees of at most T triangles), straight from each node's
+// leaf range: what the SAH top reads before it re-links everything above (whose boxes it then writes itself) -- no climb, no fences.
+// min / max are exact and associative: the same boxes as the bottom-up refit.
+__global__ void k_refit_clusters(const uint32_t* range_lo, const uint32_t* range_cnt, const float* lmin, const float* lmax, uint32_t nn, uint32_t T, float* nbox) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += gridDim.x * blockDim.x) {
+        const uint32_t cnt = range_cnt[i];
+        if (cnt > T) continue;
+        const uint32_t lo = range_lo[i];
+        float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t q = lo; q < lo + cnt; q++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                mn[j] = fmin_sel(mn[j], lmin[3 * (size_t)q + j]);
+                mx[j] = fmax_sel(mx[j], lmax[3 * (size_t)q + j]);
+            }
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            nbox[6 * (size_t)i + j] = mn[j];
+            nbox[6 * (size_t)i + 3 + j] = mx[j];
         }
     }
 }
@@ -419,7 +452,8 @@ __device__ __forceinline__ uint32_t gather_slots(uint32_t i, const uint32_t* lef
 // surface-area collapse, one four-wide level per launch: every node of the frontier survives; its live internal slots
 // form the next frontier
 __global__ void k_wide_level(const uint32_t* left, const uint32_t* right, const uint32_t* range_cnt, const float* nbox, uint32_t leaf_max,
-                             const uint32_t* frontier, uint32_t n_frontier, uint32_t* keep, uint32_t* next, uint32_t* n_next) {
+                             const uint32_t* frontier, const uint32_t* n_frontier_ptr, uint32_t* keep, uint32_t* next, uint32_t* n_next) {
+    const uint32_t n_frontier = *n_frontier_ptr;  // written by the level before: levels are launched back to back, no host round trip
     for (uint32_t f = blockIdx.x * blockDim.x + threadIdx.x; f < n_frontier; f += gridDim.x * blockDim.x) {
         const uint32_t i = frontier[f];
         keep[i] = 1u;
@@ -778,7 +812,14 @@ struct SahArrays {
     const uint32_t* pool;
     uint32_t *idx, *tmp;
     uint32_t T;
+    float* nbox;  // every re-linked node's box (the union of its clusters' boxes) is written by the kernel that splits it: no second refit
 };
+__device__ __forceinline__ void sah_store_box(const SahArrays& A, uint32_t node, const float* mn, const float* mx) {
+    for (int q = 0; q < 3; q++) {
+        A.nbox[6 * (size_t)node + q] = mn[q];
+        A.nbox[6 * (size_t)node + 3 + q] = mx[q];
+    }
+}
 __device__ __forceinline__ float sah_half_area(const float* mn, const float* mx) {
     const float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
     return (ex * ey + ey * ez) + ez * ex;
@@ -904,7 +945,7 @@ __device__ __forceinline__ uint32_t wave_sum_u(uint32_t v) {
 // fall into one to three bins) and only the wave's leader lane touches the LDS counters.  min / max / integer sums: exact in any order.
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_sah_block(SahArrays A, const SahSeg* segs, const uint32_t* n_segs, SahQueues Q) {
-    __shared__ uint32_t s_cmn[3], s_cmx[3], s_total;
+    __shared__ uint32_t s_cmn[3], s_cmx[3], s_total, s_amn[3], s_amx[3];
     __shared__ uint32_t s_bmn[3][16][3], s_bmx[3][16][3], s_bc[3][16];
     __shared__ int s_axis, s_split;
     __shared__ float s_cost[3][16];
@@ -915,8 +956,8 @@ __global__ __launch_bounds__(BLOCK) void k_sah_block(SahArrays A, const SahSeg* 
     const uint32_t node = A.pool[j.pool];
     const float inf = INFINITY;
     if (tid < 3) {
-        s_cmn[tid] = float_to_ordered(inf);
-        s_cmx[tid] = float_to_ordered(-inf);
+        s_cmn[tid] = s_amn[tid] = float_to_ordered(inf);
+        s_cmx[tid] = s_amx[tid] = float_to_ordered(-inf);
     }
     if (tid == 0) s_total = 0;
     for (uint32_t k = tid; k < 3 * 16 * 3; k += BLOCK) {
@@ -926,7 +967,7 @@ __global__ __launch_bounds__(BLOCK) void k_sah_block(SahArrays A, const SahSeg* 
     for (uint32_t k = tid; k < 3 * 16; k += BLOCK) (&s_bc[0][0])[k] = 0;
     __syncthreads();
     {  // centroid bounds, triangle total
-        float tmn[3] = {inf, inf, inf}, tmx[3] = {-inf, -inf, -inf};
+        float tmn[3] = {inf, inf, inf}, tmx[3] = {-inf, -inf, -inf}, amn[3] = {inf, inf, inf}, amx[3] = {-inf, -inf, -inf};
         uint32_t tc = 0;
         for (uint32_t k0 = tid; k0 < j.n; k0 += 4 * BLOCK) {  // four independent elements per trip: this loop lives off loads in flight
             uint32_t c[4], cc[4];
@@ -950,6 +991,8 @@ __global__ __launch_bounds__(BLOCK) void k_sah_block(SahArrays A, const SahSeg* 
                     const float ce = (mn[e][a] + mx[e][a]) * 0.5f;
                     tmn[a] = fmin_sel(tmn[a], ce);
                     tmx[a] = fmax_sel(tmx[a], ce);
+                    amn[a] = fmin_sel(amn[a], mn[e][a]);
+                    amx[a] = fmax_sel(amx[a], mx[e][a]);
                 }
             }
         }
@@ -957,12 +1000,16 @@ __global__ __launch_bounds__(BLOCK) void k_sah_block(SahArrays A, const SahSeg* 
         for (int a = 0; a < 3; a++) {
             tmn[a] = wave_min_f(tmn[a]);
             tmx[a] = wave_max_f(tmx[a]);
+            amn[a] = wave_min_f(amn[a]);
+            amx[a] = wave_max_f(amx[a]);
         }
         if (lane == 0) {
             atomicAdd(&s_total, tc);
             for (int a = 0; a < 3; a++) {
                 atomicMin(&s_cmn[a], float_to_ordered(tmn[a]));
                 atomicMax(&s_cmx[a], float_to_ordered(tmx[a]));
+                atomicMin(&s_amn[a], float_to_ordered(amn[a]));
+                atomicMax(&s_amx[a], float_to_ordered(amx[a]));
             }
         }
     }
@@ -1116,6 +1163,9 @@ __global__ __launch_bounds__(BLOCK) void k_sah_block(SahArrays A, const SahSeg* 
     if (tid == 0) {
         const uint32_t total = s_total;
         A.rcnt[node] = total > A.T ? total : A.T + 1u;
+        const float bmn[3] = {ordered_to_float(s_amn[0]), ordered_to_float(s_amn[1]), ordered_to_float(s_amn[2])};
+        const float bmx[3] = {ordered_to_float(s_amx[0]), ordered_to_float(s_amx[1]), ordered_to_float(s_amx[2])};
+        sah_store_box(A, node, bmn, bmx);
         sah_patch_parent(A, j.patch, node);
         sah_emit_child(A, SahSeg{j.a, nl, j.pool + 1, node << 1}, Q);
         sah_emit_child(A, SahSeg{j.a + nl, j.n - nl, j.pool + nl, (node << 1) | 1u}, Q);
@@ -1127,7 +1177,7 @@ __global__ __launch_bounds__(BLOCK) void k_sah_block(SahArrays A, const SahSeg* 
 // order-preserving uints (min / max) and integers (sums): exact, order independent.
 constexpr uint32_t kSahTile = 2048;
 struct SahHuge {
-    uint32_t cmn[3], cmx[3], total;
+    uint32_t cmn[3], cmx[3], total, amn[3], amx[3];  // centroid bounds, triangles, box of the whole segment
     uint32_t bmn[3][16][3], bmx[3][16][3], bc[3][16];
     int axis, split;
     uint32_t nl, tile_base, ntiles;
@@ -1147,8 +1197,8 @@ __global__ void k_sahh_tiles(const SahSeg* segs, const uint32_t* n_segs, SahHuge
     }
     for (uint32_t k = threadIdx.x; k < 3 * 16; k += blockDim.x) (&h.bc[0][0])[k] = 0;
     if (threadIdx.x < 3) {
-        h.cmn[threadIdx.x] = float_to_ordered(INFINITY);
-        h.cmx[threadIdx.x] = float_to_ordered(-INFINITY);
+        h.cmn[threadIdx.x] = h.amn[threadIdx.x] = float_to_ordered(INFINITY);
+        h.cmx[threadIdx.x] = h.amx[threadIdx.x] = float_to_ordered(-INFINITY);
     }
     if (threadIdx.x == 0) {
         h.total = 0;
@@ -1168,21 +1218,26 @@ __global__ __launch_bounds__(256) void k_sahh_bounds(SahArrays A, const SahSeg* 
     const SahSeg j = segs[tl.seg];
     const uint32_t lo = tl.t * kSahTile, hi = lo + kSahTile < j.n ? lo + kSahTile : j.n;
     const float inf = INFINITY;
-    float tmn[3] = {inf, inf, inf}, tmx[3] = {-inf, -inf, -inf};
+    float tmn[3] = {inf, inf, inf}, tmx[3] = {-inf, -inf, -inf}, amn[3] = {inf, inf, inf}, amx[3] = {-inf, -inf, -inf};
     uint32_t tc = 0;
     for (uint32_t k = lo + threadIdx.x; k < hi; k += 256) {
         const uint32_t c = A.idx[j.a + k];
         tc += A.cl_cnt[c];
         for (int a = 0; a < 3; a++) {
-            const float ce = (A.cl_mn[3 * (size_t)c + a] + A.cl_mx[3 * (size_t)c + a]) * 0.5f;
+            const float mn = A.cl_mn[3 * (size_t)c + a], mx = A.cl_mx[3 * (size_t)c + a];
+            const float ce = (mn + mx) * 0.5f;
             tmn[a] = fmin_sel(tmn[a], ce);
             tmx[a] = fmax_sel(tmx[a], ce);
+            amn[a] = fmin_sel(amn[a], mn);
+            amx[a] = fmax_sel(amx[a], mx);
         }
     }
     tc = wave_sum_u(tc);
     for (int a = 0; a < 3; a++) {
         tmn[a] = wave_min_f(tmn[a]);
         tmx[a] = wave_max_f(tmx[a]);
+        amn[a] = wave_min_f(amn[a]);
+        amx[a] = wave_max_f(amx[a]);
     }
     if ((threadIdx.x & 63u) == 0) {
         SahHuge& h = hs[tl.seg];
@@ -1190,6 +1245,8 @@ __global__ __launch_bounds__(256) void k_sahh_bounds(SahArrays A, const SahSeg* 
         for (int a = 0; a < 3; a++) {
             atomicMin(&h.cmn[a], float_to_ordered(tmn[a]));
             atomicMax(&h.cmx[a], float_to_ordered(tmx[a]));
+            atomicMin(&h.amn[a], float_to_ordered(amn[a]));
+            atomicMax(&h.amx[a], float_to_ordered(amx[a]));
         }
     }
 }
@@ -1418,6 +1475,9 @@ __global__ void k_sahh_emit(SahArrays A, const SahSeg* segs, const uint32_t* n_s
     const SahHuge& h = hs[s];
     const uint32_t node = A.pool[j.pool], nl = h.nl, total = h.total;
     A.rcnt[node] = total > A.T ? total : A.T + 1u;
+    const float bmn[3] = {ordered_to_float(h.amn[0]), ordered_to_float(h.amn[1]), ordered_to_float(h.amn[2])};
+    const float bmx[3] = {ordered_to_float(h.amx[0]), ordered_to_float(h.amx[1]), ordered_to_float(h.amx[2])};
+    sah_store_box(A, node, bmn, bmx);
     sah_patch_parent(A, j.patch, node);
     sah_emit_child(A, SahSeg{j.a, nl, j.pool + 1, node << 1}, Q);
     sah_emit_child(A, SahSeg{j.a + nl, j.n - nl, j.pool + nl, (node << 1) | 1u}, Q);
@@ -1438,17 +1498,21 @@ __global__ void k_sah_small(SahArrays A, const SahSeg* segs, uint32_t n_segs) {
             continue;
         }
         const uint32_t node = A.pool[j.pool];
-        float cmn[3] = {inf, inf, inf}, cmx[3] = {-inf, -inf, -inf};
+        float cmn[3] = {inf, inf, inf}, cmx[3] = {-inf, -inf, -inf}, amn[3] = {inf, inf, inf}, amx[3] = {-inf, -inf, -inf};
         uint32_t total = 0;
         for (uint32_t k = 0; k < j.n; k++) {
             const uint32_t c = A.idx[j.a + k];
             total += A.cl_cnt[c];
             for (int a = 0; a < 3; a++) {
-                const float ce = (A.cl_mn[3 * (size_t)c + a] + A.cl_mx[3 * (size_t)c + a]) * 0.5f;
+                const float mn = A.cl_mn[3 * (size_t)c + a], mx = A.cl_mx[3 * (size_t)c + a];
+                const float ce = (mn + mx) * 0.5f;
                 cmn[a] = fmin_sel(cmn[a], ce);
                 cmx[a] = fmax_sel(cmx[a], ce);
+                amn[a] = fmin_sel(amn[a], mn);
+                amx[a] = fmax_sel(amx[a], mx);
             }
         }
+        sah_store_box(A, node, amn, amx);
         float best_cost = inf;
         int best_axis = -1, best_split = 0;
         for (int a = 0; a < 3; a++) {
@@ -1499,7 +1563,7 @@ __global__ void k_sah_small(SahArrays A, const SahSeg* segs, uint32_t n_segs) {
 
 // returns hipSuccess and *relinked = false when the tree has fewer than three clusters (nothing to do, like the host path)
 static hipError_t sah_top_relink_gpu(hipStream_t st, uint32_t n, uint32_t nn, uint32_t* left, uint32_t* right, uint32_t* rcnt, uint32_t* pint, uint32_t* pleaf,
-                                     const float* lmin, const float* lmax, const float* nbox, uint32_t T, bool* relinked) {
+                                     const float* lmin, const float* lmax, float* nbox, uint32_t T, BuildArena& arena, bool* relinked) {
     *relinked = false;
     hipError_t err = hipSuccess;
     uint32_t *top = nullptr, *ncl = nullptr, *pool_pos = nullptr, *cl_pos = nullptr, *pool = nullptr, *cl_ref = nullptr, *cl_cnt = nullptr, *idx = nullptr, *tmp = nullptr,
@@ -1518,13 +1582,13 @@ static hipError_t sah_top_relink_gpu(hipStream_t st, uint32_t n, uint32_t nn, ui
         err = (x);              \
         if (err != hipSuccess) goto sah_done; \
     } while (0)
-    SAH_CHECK(hipMalloc(&top, (size_t)nn * 4));
-    SAH_CHECK(hipMalloc(&ncl, (size_t)nn * 4));
-    SAH_CHECK(hipMalloc(&pool_pos, (size_t)nn * 4));
-    SAH_CHECK(hipMalloc(&cl_pos, (size_t)nn * 4));
+    SAH_CHECK(arena.take(&top, (size_t)nn * 4));
+    SAH_CHECK(arena.take(&ncl, (size_t)nn * 4));
+    SAH_CHECK(arena.take(&pool_pos, (size_t)nn * 4));
+    SAH_CHECK(arena.take(&cl_pos, (size_t)nn * 4));
     hipLaunchKernelGGL(k_sah_mark, dim3(grid), dim3(256), 0, st, left, right, rcnt, nn, T, top, ncl);
     SAH_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, top, pool_pos, (int)nn, st));
-    SAH_CHECK(hipMalloc(&scan_tmp, scan_bytes ? scan_bytes : 16));
+    SAH_CHECK(arena.take(&scan_tmp, scan_bytes ? scan_bytes : 16));
     SAH_CHECK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, top, pool_pos, (int)nn, st));
     SAH_CHECK(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, ncl, cl_pos, (int)nn, st));
     SAH_CHECK(hipMemcpyAsync(&tails[0], pool_pos + (nn - 1), 4, hipMemcpyDeviceToHost, st));
@@ -1536,29 +1600,29 @@ static hipError_t sah_top_relink_gpu(hipStream_t st, uint32_t n, uint32_t nn, ui
     nc = tails[2] + tails[3];
     if (nc < 3 || npool != nc - 1) goto sah_done;  // (the host path's `return false`)
     (void)n;
-    SAH_CHECK(hipMalloc(&pool, (size_t)npool * 4));
-    SAH_CHECK(hipMalloc(&cl_ref, (size_t)nc * 4));
-    SAH_CHECK(hipMalloc(&cl_cnt, (size_t)nc * 4));
-    SAH_CHECK(hipMalloc(&cl_mn, (size_t)nc * 12));
-    SAH_CHECK(hipMalloc(&cl_mx, (size_t)nc * 12));
-    SAH_CHECK(hipMalloc(&idx, (size_t)nc * 4));
-    SAH_CHECK(hipMalloc(&tmp, (size_t)nc * 4));
-    SAH_CHECK(hipMalloc(&seg_a, 2 * ((size_t)nc / kSahSmall + 2) * sizeof(SahSeg)));  // [huge | big] of the current level
-    SAH_CHECK(hipMalloc(&seg_b, 2 * ((size_t)nc / kSahSmall + 2) * sizeof(SahSeg)));  // ... of the next one
-    SAH_CHECK(hipMalloc(&seg_small, ((size_t)nc / 2 + 2) * sizeof(SahSeg)));
-    SAH_CHECK(hipMalloc(&counters, 64));
+    SAH_CHECK(arena.take(&pool, (size_t)npool * 4));
+    SAH_CHECK(arena.take(&cl_ref, (size_t)nc * 4));
+    SAH_CHECK(arena.take(&cl_cnt, (size_t)nc * 4));
+    SAH_CHECK(arena.take(&cl_mn, (size_t)nc * 12));
+    SAH_CHECK(arena.take(&cl_mx, (size_t)nc * 12));
+    SAH_CHECK(arena.take(&idx, (size_t)nc * 4));
+    SAH_CHECK(arena.take(&tmp, (size_t)nc * 4));
+    SAH_CHECK(arena.take(&seg_a, 2 * ((size_t)nc / kSahSmall + 2) * sizeof(SahSeg)));  // [huge | big] of the current level
+    SAH_CHECK(arena.take(&seg_b, 2 * ((size_t)nc / kSahSmall + 2) * sizeof(SahSeg)));  // ... of the next one
+    SAH_CHECK(arena.take(&seg_small, ((size_t)nc / 2 + 2) * sizeof(SahSeg)));
+    SAH_CHECK(arena.take(&counters, 64));
     SAH_CHECK(hipMemsetAsync(counters, 0, 64, st));
     {
         const size_t mh = (size_t)nc / kSahHuge + 1, mt = (size_t)nc / kSahTile + mh + 1;
-        SAH_CHECK(hipMalloc(&hs, mh * sizeof(SahHuge)));
-        SAH_CHECK(hipMalloc(&tiles, mt * sizeof(SahTile)));
-        SAH_CHECK(hipMalloc(&tile_left, mt * 4));
-        SAH_CHECK(hipMalloc(&tile_woff, mt * 4));
-        SAH_CHECK(hipMalloc(&tile_roff, mt * 4));
+        SAH_CHECK(arena.take(&hs, mh * sizeof(SahHuge)));
+        SAH_CHECK(arena.take(&tiles, mt * sizeof(SahTile)));
+        SAH_CHECK(arena.take(&tile_left, mt * 4));
+        SAH_CHECK(arena.take(&tile_woff, mt * 4));
+        SAH_CHECK(arena.take(&tile_roff, mt * 4));
     }
     hipLaunchKernelGGL(k_sah_gather, dim3(grid), dim3(256), 0, st, left, right, rcnt, nn, T, top, pool_pos, cl_pos, lmin, lmax, nbox, pool, cl_ref, cl_cnt, cl_mn, cl_mx, idx);
     {
-        SahArrays A{left, right, rcnt, pint, pleaf, cl_ref, cl_cnt, cl_mn, cl_mx, pool, idx, tmp, T};
+        SahArrays A{left, right, rcnt, pint, pleaf, cl_ref, cl_cnt, cl_mn, cl_mx, pool, idx, tmp, T, nbox};
         const size_t half = (size_t)nc / kSahSmall + 2;
         const SahSeg root{0, nc, 0, 0xFFFFFFFFu};
         // counters: [0..2] huge / big segment counts of the level being processed + spare, [4..6] of the next level, [8] small segments
@@ -1622,10 +1686,6 @@ static hipError_t sah_top_relink_gpu(hipStream_t st, uint32_t n, uint32_t nn, ui
     }
 sah_done:
 #undef SAH_CHECK
-    for (void* p : {(void*)top, (void*)ncl, (void*)pool_pos, (void*)cl_pos, (void*)pool, (void*)cl_ref, (void*)cl_cnt, (void*)idx, (void*)tmp, (void*)counters,
-                    (void*)cl_mn, (void*)cl_mx, (void*)seg_a, (void*)seg_b, (void*)seg_small, scan_tmp, (void*)hs, (void*)tiles, (void*)tile_left, (void*)tile_woff,
-                    (void*)tile_roff})
-        (void)hipFree(p);
     return err;
 }
 
@@ -1640,7 +1700,7 @@ sah_done:
 
 hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,
                       const uint32_t* first_prim, uint32_t n, uint32_t leaf_max, uint32_t node_width, uint32_t node_quant, uint32_t collapse_mode,
-                      uint32_t sah_top, uint32_t sah_device, LbvhResult* out) {
+                      uint32_t sah_top, uint32_t sah_device, BuildArena& arena, LbvhResult* out) {
     hipError_t err = hipSuccess;
     *out = LbvhResult{};
     out->n_tris = n;
@@ -1667,44 +1727,53 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
         init_bounds[6 + k] = 0xFFFFFFFFu;
         init_bounds[9 + k] = 0u;
     }
-    LB_CHECK(hipMalloc(&bmin, (size_t)n * 12));
-    LB_CHECK(hipMalloc(&bmax, (size_t)n * 12));
-    LB_CHECK(hipMalloc(&lmin, (size_t)n * 12));
-    LB_CHECK(hipMalloc(&lmax, (size_t)n * 12));
-    LB_CHECK(hipMalloc(&nbox, (size_t)nn * 24));
-    LB_CHECK(hipMalloc(&bounds, 64));
-    LB_CHECK(hipMalloc(&keys_in, (size_t)n * 8));
-    LB_CHECK(hipMalloc(&keys_out, (size_t)n * 8));
-    LB_CHECK(hipMalloc(&vals_in, (size_t)n * 4));
-    LB_CHECK(hipMalloc(&vals_out, (size_t)n * 4));
-    LB_CHECK(hipMalloc(&left, (size_t)nn * 4));
-    LB_CHECK(hipMalloc(&right, (size_t)nn * 4));
-    LB_CHECK(hipMalloc(&pint, (size_t)nn * 4));
-    LB_CHECK(hipMalloc(&pleaf, (size_t)n * 4));
-    LB_CHECK(hipMalloc(&arrive, (size_t)nn * 4));
-    LB_CHECK(hipMalloc(&rlo, (size_t)nn * 4));
-    LB_CHECK(hipMalloc(&rcnt, (size_t)nn * 4));
-    LB_CHECK(hipMalloc(&keep, (size_t)nn * 4));
-    LB_CHECK(hipMalloc(&newidx, (size_t)nn * 4));
-    LB_CHECK(hipMalloc(&levels, 4));
+    {
+        // everything below comes out of one block.  Per triangle: 4 x 12 (boxes) + 24 (node boxes) + 24 (sort keys / values) + 9 x 4
+        // (links, ranges, flags) + 64 (compact layout only) + 8 (collapse frontier) + 16 + 44 + 12 (SAH top: marks, clusters,
+        // segment queues) = 276 bytes, rounded up, plus the library scans' / sort's own scratch and the alignment of ~70 pieces
+        size_t sort_bytes = 0, scan_bytes = 0;
+        LB_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, 63, st));
+        LB_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, keep, newidx, (int)nn, st));
+        LB_CHECK(arena.reserve((size_t)n * 320 + sort_bytes + 2 * scan_bytes + ((size_t)1 << 20)));
+    }
+    LB_CHECK(arena.take(&bmin, (size_t)n * 12));
+    LB_CHECK(arena.take(&bmax, (size_t)n * 12));
+    LB_CHECK(arena.take(&lmin, (size_t)n * 12));
+    LB_CHECK(arena.take(&lmax, (size_t)n * 12));
+    LB_CHECK(arena.take(&nbox, (size_t)nn * 24));
+    LB_CHECK(arena.take(&bounds, 64));
+    LB_CHECK(arena.take(&keys_in, (size_t)n * 8));
+    LB_CHECK(arena.take(&keys_out, (size_t)n * 8));
+    LB_CHECK(arena.take(&vals_in, (size_t)n * 4));
+    LB_CHECK(arena.take(&vals_out, (size_t)n * 4));
+    LB_CHECK(arena.take(&left, (size_t)nn * 4));
+    LB_CHECK(arena.take(&right, (size_t)nn * 4));
+    LB_CHECK(arena.take(&pint, (size_t)nn * 4));
+    LB_CHECK(arena.take(&pleaf, (size_t)n * 4));
+    LB_CHECK(arena.take(&arrive, (size_t)nn * 4));
+    LB_CHECK(arena.take(&rlo, (size_t)nn * 4));
+    LB_CHECK(arena.take(&rcnt, (size_t)nn * 4));
+    LB_CHECK(arena.take(&keep, (size_t)nn * 4));
+    LB_CHECK(arena.take(&newidx, (size_t)nn * 4));
+    LB_CHECK(arena.take(&levels, 4));
     LB_CHECK(hipMalloc(&out->tris, (size_t)n * 48 + 128));  // + slack: the traversal fetch may over-read the last leaf by up to 128 B
     LB_CHECK(hipMemsetAsync((char*)out->tris + (size_t)n * 48, 0, 128, st));
     LB_CHECK(hipMalloc(&out->tri_shade, (size_t)n * 64));
     if (quant == 2 && n > 1) {
-        LB_CHECK(hipMalloc(&tris_morton, (size_t)n * 48));
-        LB_CHECK(hipMalloc(&n_int, (size_t)nn * 4));
-        LB_CHECK(hipMalloc(&n_ltri, (size_t)nn * 4));
-        LB_CHECK(hipMalloc(&cbase, (size_t)nn * 4));
-        LB_CHECK(hipMalloc(&tbase, (size_t)nn * 4));
+        LB_CHECK(arena.take(&tris_morton, (size_t)n * 48));
+        LB_CHECK(arena.take(&n_int, (size_t)nn * 4));
+        LB_CHECK(arena.take(&n_ltri, (size_t)nn * 4));
+        LB_CHECK(arena.take(&cbase, (size_t)nn * 4));
+        LB_CHECK(arena.take(&tbase, (size_t)nn * 4));
     }
     LB_CHECK(hipMemcpyAsync(bounds, init_bounds, sizeof(init_bounds), hipMemcpyHostToDevice, st));
     LB_CHECK(hipMemsetAsync(arrive, 0, (size_t)nn * 4, st));
     LB_CHECK(hipMemsetAsync(levels, 0, 4, st));
-    hipLaunchKernelGGL(k_prim_bounds, dim3(grid), dim3(256), 0, st, verts, indices, geoms, prim_geom, first_prim, n, bmin, bmax, bounds);
+    hipLaunchKernelGGL(k_prim_bounds, dim3(grid > 512 ? 512 : grid), dim3(256), 0, st, verts, indices, geoms, prim_geom, first_prim, n, bmin, bmax, bounds);
     hipLaunchKernelGGL(k_tri_shade, dim3(grid), dim3(256), 0, st, verts, indices, geoms, prim_geom, first_prim, n, out->tri_shade);
     hipLaunchKernelGGL(k_morton, dim3(grid), dim3(256), 0, st, bmin, bmax, bounds, n, keys_in, vals_in);
     LB_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, 63, st));
-    LB_CHECK(hipMalloc(&temp, temp_bytes ? temp_bytes : 16));
+    LB_CHECK(arena.take(&temp, temp_bytes ? temp_bytes : 16));
     LB_CHECK(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, 63, st));
     hipLaunchKernelGGL(k_leaves, dim3(grid), dim3(256), 0, st, verts, indices, geoms, prim_geom, first_prim, vals_out, bmin, bmax, bounds, n,
                        tris_morton ? tris_morton : out->tris, lmin, lmax);
@@ -1717,19 +1786,22 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
         LB_CHECK(hipStreamSynchronize(st));
     } else {
         hipLaunchKernelGGL(k_hierarchy, dim3(grid), dim3(256), 0, st, keys_out, (int)n, left, right, pint, pleaf, rlo, rcnt);
-        hipLaunchKernelGGL(k_refit, dim3(grid), dim3(256), 0, st, left, right, pint, pleaf, lmin, lmax, n, nbox, arrive);
-        if (sah_top && sah_device) {  // re-link the upper tree by binned SAH on the GPU (bit-identical to the host path below), then refit again
-            const uint32_t T = sah_top > leaf_max ? sah_top : leaf_max;
+        const uint32_t T_sah = sah_top > leaf_max ? sah_top : leaf_max;
+        const bool lite = sah_top && sah_device && T_sah <= 64;  // the SAH top only reads the cluster boxes and writes every box above them itself
+        if (lite) hipLaunchKernelGGL(k_refit_clusters, dim3(grid), dim3(256), 0, st, rlo, rcnt, lmin, lmax, nn, T_sah, nbox);
+        else hipLaunchKernelGGL(k_refit, dim3(grid), dim3(256), 0, st, left, right, pint, pleaf, lmin, lmax, n, nbox, arrive);
+        if (sah_top && sah_device) {  // re-link the upper tree by binned SAH on the GPU (bit-identical to the host path below)
+            const uint32_t T = T_sah;
             bool relinked = false;
             const auto t0 = std::chrono::steady_clock::now();
-            LB_CHECK(sah_top_relink_gpu(st, n, nn, left, right, rcnt, pint, pleaf, lmin, lmax, nbox, T, &relinked));
-            if (relinked) {
+            LB_CHECK(sah_top_relink_gpu(st, n, nn, left, right, rcnt, pint, pleaf, lmin, lmax, nbox, T, arena, &relinked));
+            if (!relinked && lite) {  // fewer than three clusters: the Karras tree stands, and its upper boxes are still to come
                 LB_CHECK(hipMemsetAsync(arrive, 0, (size_t)nn * 4, st));
                 hipLaunchKernelGGL(k_refit, dim3(grid), dim3(256), 0, st, left, right, pint, pleaf, lmin, lmax, n, nbox, arrive);
             }
             if (getenv("RT3_TRACE_BUILD")) {
                 LB_CHECK(hipStreamSynchronize(st));
-                fprintf(stderr, "rt3 build: device SAH top (incl. GPU LBVH drain) + second refit %.2f ms\n",
+                fprintf(stderr, "rt3 build: device SAH top (incl. GPU LBVH drain) %.2f ms\n",
                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
             }
         } else if (sah_top) {  // the same re-link on the host (RT3_OPT_SAH_TOP_DEVICE = 0)
@@ -1776,27 +1848,34 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
         }
         const auto t3 = std::chrono::steady_clock::now();
         if (collapse) {
-            // top-down, one four-wide level per launch (the frontier of level l+1 is produced by level l); ~log4(n) launches
-            uint32_t *fr_a = nullptr, *fr_b = nullptr, *fr_n = nullptr, n_front = 1, wide_levels = 0;
-            const uint32_t root = 0;
-            hipError_t e2 = hipMalloc(&fr_a, (size_t)nn * 4);
-            if (e2 == hipSuccess) e2 = hipMalloc(&fr_b, (size_t)nn * 4);
-            if (e2 == hipSuccess) e2 = hipMalloc(&fr_n, 4);
+            // top-down, one four-wide level per launch (the frontier of level l+1 is produced by level l); ~log4(n) launches, sixteen at a
+            // time between looks at the frontier counters (fr_n[l] = size of level l's frontier)
+            uint32_t *fr_a = nullptr, *fr_b = nullptr, *fr_n = nullptr, wide_levels = 0;
+            const uint32_t root = 0, one = 1;
+            const size_t n_cnt = (size_t)nn + 18;  // a level per node at most, plus one burst
+            hipError_t e2 = arena.take(&fr_a, (size_t)nn * 4);
+            if (e2 == hipSuccess) e2 = arena.take(&fr_b, (size_t)nn * 4);
+            if (e2 == hipSuccess) e2 = arena.take(&fr_n, n_cnt * 4);
             if (e2 == hipSuccess) e2 = hipMemsetAsync(keep, 0, (size_t)nn * 4, st);
+            if (e2 == hipSuccess) e2 = hipMemsetAsync(fr_n, 0, n_cnt * 4, st);
             if (e2 == hipSuccess) e2 = hipMemcpyAsync(fr_a, &root, 4, hipMemcpyHostToDevice, st);
-            while (e2 == hipSuccess && n_front > 0) {
-                e2 = hipMemsetAsync(fr_n, 0, 4, st);
-                if (e2 != hipSuccess) break;
-                const unsigned g2 = (unsigned)((n_front + 255) / 256 > 4096 ? 4096 : (n_front + 255) / 256);
-                hipLaunchKernelGGL(k_wide_level, dim3(g2), dim3(256), 0, st, left, right, rcnt, nbox, leaf_max, fr_a, n_front, keep, fr_b, fr_n);
-                e2 = hipMemcpyAsync(&n_front, fr_n, 4, hipMemcpyDeviceToHost, st);
+            if (e2 == hipSuccess) e2 = hipMemcpyAsync(fr_n, &one, 4, hipMemcpyHostToDevice, st);
+            const unsigned g2 = (unsigned)((nn + 255) / 256 > 1024 ? 1024 : (nn + 255) / 256);
+            uint32_t level = 0, last = 1;
+            while (e2 == hipSuccess && last > 0 && level + 16 < n_cnt) {
+                for (int burst = 0; burst < 16; burst++, level++) {
+                    hipLaunchKernelGGL(k_wide_level, dim3(g2), dim3(256), 0, st, left, right, rcnt, nbox, leaf_max, fr_a, fr_n + level, keep, fr_b, fr_n + level + 1);
+                    std::swap(fr_a, fr_b);
+                }
+                e2 = hipMemcpyAsync(&last, fr_n + level, 4, hipMemcpyDeviceToHost, st);
                 if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
-                std::swap(fr_a, fr_b);
-                ++wide_levels;
             }
-            (void)hipFree(fr_a);
-            (void)hipFree(fr_b);
-            (void)hipFree(fr_n);
+            if (e2 == hipSuccess) {  // the number of non-empty frontiers
+                std::vector<uint32_t> h_cnt(level + 1);
+                e2 = hipMemcpyAsync(h_cnt.data(), fr_n, (size_t)(level + 1) * 4, hipMemcpyDeviceToHost, st);
+                if (e2 == hipSuccess) e2 = hipStreamSynchronize(st);
+                while (wide_levels <= level && h_cnt[wide_levels] > 0) wide_levels++;
+            }
             LB_CHECK(e2);
             const uint32_t lv = wide_levels + 1;  // levels from the root down to the deepest node's leaf slots
             LB_CHECK(hipMemcpyAsync(levels, &lv, 4, hipMemcpyHostToDevice, st));
@@ -1805,7 +1884,7 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
             hipLaunchKernelGGL(k_keep_flags, dim3(grid), dim3(256), 0, st, pint, rcnt, nn, leaf_max, wide, keep, levels);
         }
         LB_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, temp2_bytes, keep, newidx, (int)nn, st));
-        LB_CHECK(hipMalloc(&temp2, temp2_bytes ? temp2_bytes : 16));
+        LB_CHECK(arena.take(&temp2, temp2_bytes ? temp2_bytes : 16));
         LB_CHECK(hipcub::DeviceScan::ExclusiveSum(temp2, temp2_bytes, keep, newidx, (int)nn, st));
         LB_CHECK(hipMemcpyAsync(&tail[0], newidx + (nn - 1), 4, hipMemcpyDeviceToHost, st));
         LB_CHECK(hipMemcpyAsync(&tail[1], keep + (nn - 1), 4, hipMemcpyDeviceToHost, st));
@@ -1824,11 +1903,10 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
         if (wide && quant == 1) {  // top-of-tree copy the traversal kernels keep in LDS
             uint32_t* d_ntop = nullptr;
             LB_CHECK(hipMalloc(&out->top, (size_t)kTopCacheNodes * 64));
-            LB_CHECK(hipMalloc(&d_ntop, 4));
+            LB_CHECK(arena.take(&d_ntop, 4));
             hipLaunchKernelGGL(k_top_cache, dim3(1), dim3(1), 0, st, out->nodes, out->n_nodes, (uint32_t*)out->top, d_ntop);
             hipError_t e3 = hipMemcpyAsync(&out->n_top, d_ntop, 4, hipMemcpyDeviceToHost, st);
             if (e3 == hipSuccess) e3 = hipStreamSynchronize(st);
-            (void)hipFree(d_ntop);
             LB_CHECK(e3);
         }
         LB_CHECK(hipGetLastError());
@@ -1837,10 +1915,6 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
             fprintf(stderr, "rt3 build: collapse + emit %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t3).count());
     }
 done:
-    for (void* p : {(void*)bmin, (void*)bmax, (void*)lmin, (void*)lmax, (void*)nbox, (void*)bounds, (void*)keys_in, (void*)keys_out, (void*)vals_in,
-                    (void*)vals_out, (void*)left, (void*)right, (void*)pint, (void*)pleaf, (void*)arrive, (void*)levels, (void*)rlo, (void*)rcnt,
-                    (void*)keep, (void*)newidx, (void*)n_int, (void*)n_ltri, (void*)cbase, (void*)tbase, (void*)tris_morton, temp, temp2})
-        (void)hipFree(p);
     if (stage) (void)hipHostFree(stage);
     if (err != hipSuccess) {
         (void)hipFree(out->nodes);
