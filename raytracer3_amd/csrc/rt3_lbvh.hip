@@ -924,20 +924,40 @@ __device__ __forceinline__ void sah_emit_child(const SahArrays& A, SahSeg c, con
     else if (c.n > kSahSmall) Q.big[atomicAdd(&Q.counts[1], 1u)] = c;
     else Q.small[atomicAdd(Q.n_small, 1u)] = c;
 }
+// Reductions over a FULL wave (all 64 lanes active -- every caller iterates whole waves): four DPP steps inside each row of 16 lanes
+// (quad xor 1, quad xor 2, half-row mirror, row mirror), then the four row results through v_readlane.  ~15 instructions; the
+// __shfl_xor butterfly these replace is six dependent ds_bpermute round trips through the LDS crossbar (~800 cycles).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+__device__ __forceinline__ float lane_f(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 __device__ __forceinline__ float wave_min_f(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmin_sel(v, __shfl_xor(v, m));
-    return v;
+    v = fmin_sel(v, dpp_f<kDppXor1>(v));
+    v = fmin_sel(v, dpp_f<kDppXor2>(v));
+    v = fmin_sel(v, dpp_f<kDppHalfMirror>(v));
+    v = fmin_sel(v, dpp_f<kDppMirror>(v));
+    return fmin_sel(fmin_sel(lane_f(v, 0), lane_f(v, 16)), fmin_sel(lane_f(v, 32), lane_f(v, 48)));
 }
 __device__ __forceinline__ float wave_max_f(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmax_sel(v, __shfl_xor(v, m));
-    return v;
+    v = fmax_sel(v, dpp_f<kDppXor1>(v));
+    v = fmax_sel(v, dpp_f<kDppXor2>(v));
+    v = fmax_sel(v, dpp_f<kDppHalfMirror>(v));
+    v = fmax_sel(v, dpp_f<kDppMirror>(v));
+    return fmax_sel(fmax_sel(lane_f(v, 0), lane_f(v, 16)), fmax_sel(lane_f(v, 32), lane_f(v, 48)));
 }
 __device__ __forceinline__ uint32_t wave_sum_u(uint32_t v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    return v;
+    v += dpp_u<kDppXor1>(v);
+    v += dpp_u<kDppXor2>(v);
+    v += dpp_u<kDppHalfMirror>(v);
+    v += dpp_u<kDppMirror>(v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 0) + (uint32_t)__builtin_amdgcn_readlane((int)v, 16) + (uint32_t)__builtin_amdgcn_readlane((int)v, 32) +
+           (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
 }
 
 // One workgroup per segment.  Contention-free by construction: centroid bounds are reduced in registers and then across the wave;
@@ -949,7 +969,13 @@ __global__ __launch_bounds__(BLOCK) void k_sah_block(SahArrays A, const SahSeg* 
     __shared__ uint32_t s_bmn[3][16][3], s_bmx[3][16][3], s_bc[3][16];
     __shared__ int s_axis, s_split;
     __shared__ float s_cost[3][16];
-    __shared__ uint32_t s_w, s_r, s_wave[BLOCK / 64][2];
+    // the segment's cluster ids and their three bin numbers, staged once: the partition then needs no global read at all and places
+    // every element directly (ranks from one scan over per-wave counts) -- it was 3 barriers and two dependent loads per 256 elements
+    constexpr int NW = BLOCK / 64, NE = (int)kSahHuge / BLOCK;
+    static_assert(NW * NE == 64, "one wave scans the per-(chunk, wave) counts");
+    __shared__ uint32_t s_c[kSahHuge];
+    __shared__ uint16_t s_bins[kSahHuge];
+    __shared__ uint32_t s_offl[64], s_offr[64], s_nl;
     if (blockIdx.x >= *n_segs) return;  // the grid is sized for the most segments a level can have: no host round trip per level
     const SahSeg j = segs[blockIdx.x];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -977,6 +1003,7 @@ __global__ __launch_bounds__(BLOCK) void k_sah_block(SahArrays A, const SahSeg* 
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 const bool ok = c[e] != 0xFFFFFFFFu;
+                if (ok) s_c[k0 + e * BLOCK] = c[e];
                 cc[e] = ok ? A.cl_cnt[c[e]] : 0u;
                 for (int a = 0; a < 3; a++) {
                     mn[e][a] = ok ? A.cl_mn[3 * (size_t)c[e] + a] : 0.0f;
@@ -1024,7 +1051,7 @@ __global__ __launch_bounds__(BLOCK) void k_sah_block(SahArrays A, const SahSeg* 
         uint32_t ce4[4], cnt4[4];
         float mn4[4][3], mx4[4][3];
 #pragma unroll
-        for (int e = 0; e < 4; e++) ce4[e] = k0 + e * BLOCK < j.n ? A.idx[j.a + k0 + e * BLOCK] : 0xFFFFFFFFu;
+        for (int e = 0; e < 4; e++) ce4[e] = k0 + e * BLOCK < j.n ? s_c[k0 + e * BLOCK] : 0xFFFFFFFFu;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             const bool ok = ce4[e] != 0xFFFFFFFFu;
@@ -1041,20 +1068,24 @@ __global__ __launch_bounds__(BLOCK) void k_sah_block(SahArrays A, const SahSeg* 
             const uint32_t cnt = cnt4[e];
             const float* mn = mn4[e];
             const float* mx = mx4[e];
+            uint32_t packed = 0;
             for (int a = 0; a < 3; a++) {
                 if (!(ext[a] > 0.0f)) continue;  // (uniform over the workgroup)
                 const int b = valid ? sah_bin((mn[a] + mx[a]) * 0.5f, cmn[a], ext[a]) : -1;
-                unsigned long long todo = __ballot(valid);
-                while (todo) {  // one round per distinct bin among the wave's lanes
-                    const int leader = __ffsll((long long)todo) - 1;
-                    const int bb = __shfl(b, leader);
-                    const bool mine = b == bb;
-                    const unsigned long long peers = __ballot(mine);
-                    const uint32_t sc = wave_sum_u(mine ? cnt : 0u);
+                packed |= valid ? (uint32_t)b << (4 * a) : 0u;
+                // a wave's 64 consecutive clusters (Morton sub-order) share one bin in the big segments near the root: one reduction
+                // across the wave and seven LDS atomics by its first lane.  Otherwise every lane adds its own cluster: lanes of one
+                // bin serialise inside the atomic, the others proceed in parallel (a reduction round per distinct bin cost more)
+                const unsigned long long vmask = __ballot(valid);
+                if (vmask == 0ull) continue;
+                const int leader = __ffsll((long long)vmask) - 1;
+                const int bb = __builtin_amdgcn_readlane(b, leader);
+                if (__ballot(valid && b == bb) == vmask) {
+                    const uint32_t sc = wave_sum_u(cnt);  // (idle lanes carry 0 / +inf / -inf)
                     float rmn[3], rmx[3];
                     for (int q = 0; q < 3; q++) {
-                        rmn[q] = wave_min_f(mine ? mn[q] : inf);
-                        rmx[q] = wave_max_f(mine ? mx[q] : -inf);
+                        rmn[q] = wave_min_f(mn[q]);
+                        rmx[q] = wave_max_f(mx[q]);
                     }
                     if ((int)lane == leader) {
                         atomicAdd(&s_bc[a][bb], sc);
@@ -1063,9 +1094,15 @@ __global__ __launch_bounds__(BLOCK) void k_sah_block(SahArrays A, const SahSeg* 
                             atomicMax(&s_bmx[a][bb][q], float_to_ordered(rmx[q]));
                         }
                     }
-                    todo &= ~peers;
+                } else if (valid) {
+                    atomicAdd(&s_bc[a][b], cnt);
+                    for (int q = 0; q < 3; q++) {
+                        atomicMin(&s_bmn[a][b][q], float_to_ordered(mn[q]));
+                        atomicMax(&s_bmx[a][b][q], float_to_ordered(mx[q]));
+                    }
                 }
             }
+            if (valid) s_bins[k0 + e * BLOCK] = (uint16_t)packed;
         }
     }
     __syncthreads();
@@ -1106,8 +1143,6 @@ __global__ __launch_bounds__(BLOCK) void k_sah_block(SahArrays A, const SahSeg* 
                 }
         s_axis = best_axis;
         s_split = best_split;
-        s_w = 0;
-        s_r = 0;
     }
     __syncthreads();
     const int axis = s_axis, split = s_split;
@@ -1115,50 +1150,53 @@ __global__ __launch_bounds__(BLOCK) void k_sah_block(SahArrays A, const SahSeg* 
     if (axis < 0) {
         nl = j.n / 2;  // coincident centroids: halve in index order
     } else {
-        // stable partition, in place, BLOCK elements at a time: lefts go to idx[a + w ..] (w never passes the chunk being read),
-        // rights to tmp[a + r ..] and are appended behind the lefts at the end
-        for (uint32_t base = 0; base < j.n; base += BLOCK) {
-            const uint32_t k = base + tid;
-            const bool valid = k < j.n;
-            uint32_t c = 0;
-            bool goes_left = false;
-            if (valid) {
-                c = A.idx[j.a + k];
-                const float ce = (A.cl_mn[3 * (size_t)c + axis] + A.cl_mx[3 * (size_t)c + axis]) * 0.5f;
-                goes_left = sah_bin(ce, cmn[axis], ext[axis]) < split;
+        // stable partition: lefts keep their order in idx[a ..], rights theirs behind them.  The position of element k (chunk e = k / BLOCK,
+        // wave w, lane) is the number of lefts (rights) in the (chunk, wave) pairs before (e, w) -- one 64-entry scan -- plus those below
+        // its lane in its own ballot.
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const uint32_t n_chunks = (j.n + BLOCK - 1) / BLOCK;
+        for (uint32_t e = 0; e < (uint32_t)NE; e++) {
+            uint32_t cl = 0, cr = 0;
+            if (e < n_chunks) {
+                const uint32_t k = e * BLOCK + tid;
+                const bool valid = k < j.n;
+                const bool goes_left = valid && (int)((s_bins[valid ? k : 0] >> (4 * axis)) & 15u) < split;
+                cl = (uint32_t)__popcll(__ballot(goes_left));
+                cr = (uint32_t)__popcll(__ballot(valid && !goes_left));
             }
-            const unsigned long long ml = __ballot(valid && goes_left), mr = __ballot(valid && !goes_left);
             if (lane == 0) {
-                s_wave[wave][0] = (uint32_t)__popcll(ml);
-                s_wave[wave][1] = (uint32_t)__popcll(mr);
+                s_offl[e * NW + wave] = cl;
+                s_offr[e * NW + wave] = cr;
             }
-            __syncthreads();  // every thread has read its element of this chunk
-            uint32_t wl = s_w, wr = s_r;
-            for (uint32_t q = 0; q < wave; q++) {
-                wl += s_wave[q][0];
-                wr += s_wave[q][1];
-            }
-            const unsigned long long below = (1ull << lane) - 1ull;
-            if (valid) {
-                if (goes_left) A.idx[j.a + wl + (uint32_t)__popcll(ml & below)] = c;
-                else A.tmp[j.a + wr + (uint32_t)__popcll(mr & below)] = c;
-            }
-            __syncthreads();
-            if (tid == 0) {
-                uint32_t tl = 0, tr = 0;
-                for (int q = 0; q < BLOCK / 64; q++) {
-                    tl += s_wave[q][0];
-                    tr += s_wave[q][1];
-                }
-                s_w += tl;
-                s_r += tr;
-            }
-            __syncthreads();
         }
-        nl = s_w;
-        const uint32_t nr = s_r;
-        for (uint32_t k = tid; k < nr; k += BLOCK) A.idx[j.a + nl + k] = A.tmp[j.a + k];
         __syncthreads();
+        if (wave == 0) {  // exclusive scan of the 64 counts
+            const uint32_t vl = s_offl[lane], vr = s_offr[lane];
+            uint32_t il = vl, ir = vr;
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) {
+                const uint32_t tl = __shfl_up(il, m), tr = __shfl_up(ir, m);
+                if ((int)lane >= m) {
+                    il += tl;
+                    ir += tr;
+                }
+            }
+            s_offl[lane] = il - vl;
+            s_offr[lane] = ir - vr;
+            if (lane == 63) s_nl = il;
+        }
+        __syncthreads();
+        nl = s_nl;
+        for (uint32_t e = 0; e < n_chunks; e++) {
+            const uint32_t k = e * BLOCK + tid;
+            const bool valid = k < j.n;
+            const bool goes_left = valid && (int)((s_bins[valid ? k : 0] >> (4 * axis)) & 15u) < split;
+            const unsigned long long ml = __ballot(goes_left), mr = __ballot(valid && !goes_left);
+            if (valid) {
+                const uint32_t pos = goes_left ? s_offl[e * NW + wave] + (uint32_t)__popcll(ml & below) : nl + s_offr[e * NW + wave] + (uint32_t)__popcll(mr & below);
+                A.idx[j.a + pos] = s_c[k];
+            }
+        }
     }
     if (tid == 0) {
         const uint32_t total = s_total;
@@ -1286,17 +1324,16 @@ __global__ __launch_bounds__(256) void k_sahh_bins(SahArrays A, const SahSeg* se
         for (int a = 0; a < 3; a++) {
             if (!(ext[a] > 0.0f)) continue;
             const int b = valid ? sah_bin((mn[a] + mx[a]) * 0.5f, cmn[a], ext[a]) : -1;
-            unsigned long long todo = __ballot(valid);
-            while (todo) {
-                const int leader = __ffsll((long long)todo) - 1;
-                const int bb = __shfl(b, leader);
-                const bool mine = b == bb;
-                const unsigned long long peers = __ballot(mine);
-                const uint32_t sc = wave_sum_u(mine ? cnt : 0u);
+            const unsigned long long vmask = __ballot(valid);  // (k_sah_block has the argument)
+            if (vmask == 0ull) continue;
+            const int leader = __ffsll((long long)vmask) - 1;
+            const int bb = __builtin_amdgcn_readlane(b, leader);
+            if (__ballot(valid && b == bb) == vmask) {
+                const uint32_t sc = wave_sum_u(cnt);
                 float rmn[3], rmx[3];
                 for (int q = 0; q < 3; q++) {
-                    rmn[q] = wave_min_f(mine ? mn[q] : inf);
-                    rmx[q] = wave_max_f(mine ? mx[q] : -inf);
+                    rmn[q] = wave_min_f(mn[q]);
+                    rmx[q] = wave_max_f(mx[q]);
                 }
                 if ((int)lane == leader) {
                     atomicAdd(&s_bc[a][bb], sc);
@@ -1305,7 +1342,12 @@ __global__ __launch_bounds__(256) void k_sahh_bins(SahArrays A, const SahSeg* se
                         atomicMax(&s_bmx[a][bb][q], float_to_ordered(rmx[q]));
                     }
                 }
-                todo &= ~peers;
+            } else if (valid) {
+                atomicAdd(&s_bc[a][b], cnt);
+                for (int q = 0; q < 3; q++) {
+                    atomicMin(&s_bmn[a][b][q], float_to_ordered(mn[q]));
+                    atomicMax(&s_bmx[a][b][q], float_to_ordered(mx[q]));
+                }
             }
         }
     }
@@ -1483,80 +1525,145 @@ __global__ void k_sahh_emit(SahArrays A, const SahSeg* segs, const uint32_t* n_s
     sah_emit_child(A, SahSeg{j.a + nl, j.n - nl, j.pool + nl, (node << 1) | 1u}, Q);
 }
 
-// one thread per segment of at most kSahSmall clusters: sah_top_relink's loop, with a private stack
-__global__ void k_sah_small(SahArrays A, const SahSeg* segs, uint32_t n_segs) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_segs) return;
-    SahSeg st[kSahSmall + 2];
-    int sp = 0;
-    st[sp++] = segs[s];
+// Segments of at most kSahSmall clusters: sah_top_relink's loop, one 16-lane group per segment (four segments per wave).  A lane holds one
+// cluster of the sub-segment being split; the 15 split planes of each axis are costed by lanes 1..15 of the group, every lane sweeping
+// the (at most 16) clusters broadcast from their lanes -- unions of the same boxes and sums of the same counts as the bins of the
+// sequential sweep, min / max / integer adds being exact in any order -- and the group takes the first minimum in (axis, plane) order
+// like its strict `<`.  The segment's cluster order lives in LDS (the global index array is not needed past this point: single
+// clusters are linked as soon as they fall out), the sub-segment stack too.
+constexpr uint32_t kSahGroup = 16;
+static_assert(kSahGroup == kSahSmall, "a group's lanes hold a whole small segment");
+__device__ __forceinline__ float group_min_f(float v) {
+#pragma unroll
+    for (int m = kSahGroup / 2; m >= 1; m >>= 1) v = fmin_sel(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ float group_max_f(float v) {
+#pragma unroll
+    for (int m = kSahGroup / 2; m >= 1; m >>= 1) v = fmax_sel(v, __shfl_xor(v, m));
+    return v;
+}
+__device__ __forceinline__ uint32_t group_sum_u(uint32_t v) {
+#pragma unroll
+    for (int m = kSahGroup / 2; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+__global__ __launch_bounds__(256) void k_sah_small(SahArrays A, const SahSeg* segs, uint32_t n_segs) {
+    constexpr uint32_t G = kSahGroup, NG = 256 / G;
+    __shared__ uint32_t s_cl[NG][G];
+    __shared__ SahSeg s_stack[NG][G + 2];
+    const uint32_t tid = threadIdx.x, g = tid / G, l = tid % G;
+    const uint32_t s = blockIdx.x * NG + g;
+    if (s >= n_segs) return;  // (a whole group at a time)
+    const uint32_t gshift = (tid & 63u) & ~(G - 1u);  // the group's first lane within the wave
+    const unsigned long long gmask = 0xFFFFull << gshift;
+    const uint32_t below = (1u << l) - 1u;
     const float inf = INFINITY;
+    {
+        const SahSeg seg0 = segs[s];
+        if (l < seg0.n) s_cl[g][l] = A.idx[seg0.a + l];
+        if (l == 0) s_stack[g][0] = SahSeg{0u, seg0.n, seg0.pool, seg0.patch};  // .a: relative to the segment's start from here on
+    }
+    int sp = 1;
     while (sp > 0) {
-        const SahSeg j = st[--sp];
-        if (j.n == 1) {
-            sah_patch_parent(A, j.patch, A.cl_ref[A.idx[j.a]]);
-            continue;
-        }
+        __builtin_amdgcn_wave_barrier();  // (LDS is in order within a wave; this keeps the compiler from moving the reads up)
+        const SahSeg j = s_stack[g][--sp];
         const uint32_t node = A.pool[j.pool];
-        float cmn[3] = {inf, inf, inf}, cmx[3] = {-inf, -inf, -inf}, amn[3] = {inf, inf, inf}, amx[3] = {-inf, -inf, -inf};
-        uint32_t total = 0;
+        const bool valid = l < j.n;
+        const uint32_t c = valid ? s_cl[g][j.a + l] : 0u;
+        float mn[3], mx[3], ce[3];
+        const uint32_t cnt = valid ? A.cl_cnt[c] : 0u;
+        for (int q = 0; q < 3; q++) {
+            mn[q] = valid ? A.cl_mn[3 * (size_t)c + q] : inf;
+            mx[q] = valid ? A.cl_mx[3 * (size_t)c + q] : -inf;
+            ce[q] = (mn[q] + mx[q]) * 0.5f;
+        }
+        const uint32_t total = group_sum_u(cnt);
+        float cmn[3], ext[3], amn[3], amx[3];
+        int b[3];
+        for (int q = 0; q < 3; q++) {
+            cmn[q] = group_min_f(valid ? ce[q] : inf);
+            ext[q] = group_max_f(valid ? ce[q] : -inf) - cmn[q];
+            amn[q] = group_min_f(mn[q]);
+            amx[q] = group_max_f(mx[q]);
+            b[q] = (valid && ext[q] > 0.0f) ? sah_bin(ce[q], cmn[q], ext[q]) : 16;  // (an idle lane adds nothing wherever it lands)
+        }
+        // lane l: the plane between bins l-1 and l of every axis
+        float lmn[3][3], lmx[3][3], rmn[3][3], rmx[3][3];
+        uint32_t lc[3] = {0, 0, 0}, rc[3] = {0, 0, 0};
+        for (int a = 0; a < 3; a++)
+            for (int q = 0; q < 3; q++) {
+                lmn[a][q] = rmn[a][q] = inf;
+                lmx[a][q] = rmx[a][q] = -inf;
+            }
         for (uint32_t k = 0; k < j.n; k++) {
-            const uint32_t c = A.idx[j.a + k];
-            total += A.cl_cnt[c];
+            const int src = (int)(gshift + k);
+            float kmn[3], kmx[3];
+            int kb[3];
+            const uint32_t kc = __shfl(cnt, src);
+            for (int q = 0; q < 3; q++) {
+                kmn[q] = __shfl(mn[q], src);
+                kmx[q] = __shfl(mx[q], src);
+                kb[q] = __shfl(b[q], src);
+            }
             for (int a = 0; a < 3; a++) {
-                const float mn = A.cl_mn[3 * (size_t)c + a], mx = A.cl_mx[3 * (size_t)c + a];
-                const float ce = (mn + mx) * 0.5f;
-                cmn[a] = fmin_sel(cmn[a], ce);
-                cmx[a] = fmax_sel(cmx[a], ce);
-                amn[a] = fmin_sel(amn[a], mn);
-                amx[a] = fmax_sel(amx[a], mx);
+                const bool left = kb[a] < (int)l;
+                lc[a] += left ? kc : 0u;
+                rc[a] += left ? 0u : kc;
+                for (int q = 0; q < 3; q++) {
+                    lmn[a][q] = fmin_sel(lmn[a][q], left ? kmn[q] : inf);
+                    lmx[a][q] = fmax_sel(lmx[a][q], left ? kmx[q] : -inf);
+                    rmn[a][q] = fmin_sel(rmn[a][q], left ? inf : kmn[q]);
+                    rmx[a][q] = fmax_sel(rmx[a][q], left ? -inf : kmx[q]);
+                }
             }
         }
-        sah_store_box(A, node, amn, amx);
         float best_cost = inf;
-        int best_axis = -1, best_split = 0;
+        uint32_t best_key = 0xFFFFFFFFu;  // axis * 16 + plane
         for (int a = 0; a < 3; a++) {
-            const float ext = cmx[a] - cmn[a];
-            if (!(ext > 0.0f)) continue;
-            float bmn[16][3], bmx[16][3];
-            uint32_t bc[16];
-            for (int b = 0; b < 16; b++) {
-                bc[b] = 0;
-                for (int q = 0; q < 3; q++) {
-                    bmn[b][q] = inf;
-                    bmx[b][q] = -inf;
-                }
+            if (l == 0 || !(ext[a] > 0.0f) || lc[a] == 0 || rc[a] == 0) continue;
+            const float cost = sah_half_area(lmn[a], lmx[a]) * (float)lc[a] + sah_half_area(rmn[a], rmx[a]) * (float)rc[a];
+            if (cost < best_cost) {
+                best_cost = cost;
+                best_key = (uint32_t)a * 16u + l;
             }
-            for (uint32_t k = 0; k < j.n; k++) {
-                const uint32_t c = A.idx[j.a + k];
-                const int b = sah_bin((A.cl_mn[3 * (size_t)c + a] + A.cl_mx[3 * (size_t)c + a]) * 0.5f, cmn[a], ext);
-                bc[b] += A.cl_cnt[c];
-                for (int q = 0; q < 3; q++) {
-                    bmn[b][q] = fmin_sel(bmn[b][q], A.cl_mn[3 * (size_t)c + q]);
-                    bmx[b][q] = fmax_sel(bmx[b][q], A.cl_mx[3 * (size_t)c + q]);
-                }
-            }
-            sah_sweep_axis(a, bmn, bmx, bc, best_cost, best_axis, best_split);
         }
-        uint32_t nl = 0;
-        if (best_axis < 0) {
-            nl = j.n / 2;
+#pragma unroll
+        for (int m = G / 2; m >= 1; m >>= 1) {
+            const float oc = __shfl_xor(best_cost, m);
+            const uint32_t ok = __shfl_xor(best_key, m);
+            if (oc < best_cost || (oc == best_cost && ok < best_key)) {
+                best_cost = oc;
+                best_key = ok;
+            }
+        }
+        uint32_t nl, newpos = l;
+        if (best_key == 0xFFFFFFFFu) {
+            nl = j.n / 2;  // coincident centroids: halve in index order
         } else {
-            const float ext = cmx[best_axis] - cmn[best_axis];
-            uint32_t w = 0, r = 0;
-            for (uint32_t k = 0; k < j.n; k++) {
-                const uint32_t c = A.idx[j.a + k];
-                const int b = sah_bin((A.cl_mn[3 * (size_t)c + best_axis] + A.cl_mx[3 * (size_t)c + best_axis]) * 0.5f, cmn[best_axis], ext);
-                if (b < best_split) A.idx[j.a + w++] = c;
-                else A.tmp[j.a + r++] = c;
-            }
-            for (uint32_t k = 0; k < r; k++) A.idx[j.a + w + k] = A.tmp[j.a + k];
-            nl = w;
+            const int axis = (int)(best_key >> 4), split = (int)(best_key & 15u);
+            const int bx = axis == 0 ? b[0] : (axis == 1 ? b[1] : b[2]);
+            const bool gl = valid && bx < split, gr = valid && !gl;
+            const uint32_t ml = (uint32_t)((__ballot(gl) & gmask) >> gshift), mr = (uint32_t)((__ballot(gr) & gmask) >> gshift);
+            nl = (uint32_t)__popc(ml);
+            newpos = gl ? (uint32_t)__popc(ml & below) : nl + (uint32_t)__popc(mr & below);  // stable on both sides
         }
-        A.rcnt[node] = total > A.T ? total : A.T + 1u;
-        sah_patch_parent(A, j.patch, node);
-        st[sp++] = SahSeg{j.a + nl, j.n - nl, j.pool + nl, (node << 1) | 1u};
-        st[sp++] = SahSeg{j.a, nl, j.pool + 1, node << 1};
+        __builtin_amdgcn_wave_barrier();
+        if (valid) s_cl[g][j.a + newpos] = c;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t nr = j.n - nl;
+        if (l == 0) {
+            A.rcnt[node] = total > A.T ? total : A.T + 1u;
+            sah_store_box(A, node, amn, amx);
+            sah_patch_parent(A, j.patch, node);
+            const SahSeg cl{j.a, nl, j.pool + 1, node << 1}, cr{j.a + nl, nr, j.pool + nl, (node << 1) | 1u};
+            int w = sp;
+            if (nr == 1) sah_patch_parent(A, cr.patch, A.cl_ref[s_cl[g][cr.a]]);
+            else s_stack[g][w++] = cr;
+            if (nl == 1) sah_patch_parent(A, cl.patch, A.cl_ref[s_cl[g][cl.a]]);
+            else s_stack[g][w] = cl;
+        }
+        sp += (nr > 1 ? 1 : 0) + (nl > 1 ? 1 : 0);
     }
 }
 }  // namespace
@@ -1673,7 +1780,7 @@ static hipError_t sah_top_relink_gpu(hipStream_t st, uint32_t n, uint32_t nn, ui
         }
         SAH_CHECK(hipMemcpyAsync(&cnt[2], counters + 8, 4, hipMemcpyDeviceToHost, st));
         SAH_CHECK(hipStreamSynchronize(st));
-        if (cnt[2]) hipLaunchKernelGGL(k_sah_small, dim3((cnt[2] + 63) / 64), dim3(64), 0, st, A, seg_small, cnt[2]);
+        if (cnt[2]) hipLaunchKernelGGL(k_sah_small, dim3((cnt[2] + 15) / 16), dim3(256), 0, st, A, seg_small, cnt[2]);
         if (trace) {
             SAH_CHECK(hipStreamSynchronize(st));
             fprintf(stderr, "rt3 build:   SAH small: %u segments, %.3f ms (%u clusters)\n", cnt[2], std::chrono::duration<double, std::milli>(tnow() - tl).count(), nc);
