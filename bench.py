@@ -201,7 +201,8 @@ def main():
 
     W, H = args.width, args.height
     mesh = scenes.atrium(args.detail)
-    sky = scenes.sky(2048, 1024)
+    sky_w = int(os.environ.get("RT3_SKY_W", "2048"))  # (experiments: a smaller environment map)
+    sky = scenes.sky(sky_w, sky_w // 2)
     bn = assets.load_bluenoise()
     pt = PathTracer((W, H), device=device_index if world > 1 else 0, rank=rank, n_ranks=world)
     if args.leaf_size:

@@ -147,6 +147,22 @@ def test_sah_top_device_and_host_builds_are_identical(small, T):
     assert np.array_equal(out[0][1], osc.nodes()) and np.array_equal(out[0][2], osc.tris())
 
 
+def test_one_context_rebuilds_scenes_of_different_sizes(small, cornell):
+    """The builder's scratch is one arena the context keeps (BuildArena): a small scene, a large one, the small one again with another
+    SAH cluster size and with the full-refit path (T = 0), all on ONE context -- every build equals the oracle's arrays, so nothing
+    of an earlier build survives in the reused block."""
+    ctx = Context(0)
+    for mesh, T in ((cornell[0], 2), (small[0], 2), (cornell[0], 5), (small[0], 0), (small[0], 100), (cornell[0], 2)):
+        osc = orc.Scene(mesh, sah_top=T)
+        ctx.set_option(L.OPT_SAH_TOP, T)
+        ctx.upload_mesh(mesh)
+        ctx.build_accel()
+        assert ctx.accel_info()[:3] == (osc.n_nodes, osc.n_tris, osc.max_depth)
+        nodes, tris = ctx.accel_download()
+        assert np.array_equal(nodes, osc.nodes()) and np.array_equal(tris, osc.tris())
+    ctx.close()
+
+
 def test_lbvh_edge_cases():
     """empty scene, one triangle, duplicate triangles (identical Morton codes)."""
     ctx = Context(0)
@@ -820,8 +836,8 @@ def test_rccl_rendezvous_of_two_processes(tmp_path):
 
 
 def test_lbvh_large_scene_bit_identical():
-    """0.9 M triangles (atrium at 3x tessellation): GPU build (Morton sort, Karras hierarchy, refit, host SAH top, collapse,
-    quantisation) against the oracle's arrays, and 100 k rays with their visit counts."""
+    """0.9 M triangles (atrium at 3x tessellation): GPU build (Morton sort, Karras hierarchy, cluster boxes, device SAH top with its
+    tiled levels, collapse, quantisation) against the oracle's arrays, and 100 k rays with their visit counts."""
     mesh = scenes.atrium(3.0)
     assert mesh.n_triangles > 900_000
     osc = orc.Scene(mesh)
