@@ -9,7 +9,7 @@ import sys
 
 
 def short(name):
-    n = name.replace("void ", "").split("(")[0]
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
     return n[:80]
 
 
