@@ -324,7 +324,7 @@ def main():
     # tools/summarize_profile.py into profiles/*_traffic.json.  Quoted only for the default workload they were collected on AND
     # only while the kernel's average duration in that profile agrees with this run's within 5 % (a stale profile is not evidence).
     prof = None
-    if default_workload and world == 1:  # of the committed profiles, the one whose dominant-kernel time is closest to this run's
+    if default_workload and world == 1:  # of the committed profiles, the newest one whose dominant-kernel time agrees with this run's
         best_gap = None
         for tf in sorted((ROOT / "profiles").glob("r*_traffic.json")):
             tj = json.loads(tf.read_text())
@@ -332,8 +332,11 @@ def main():
             if not kk or avg_ms <= 0:
                 continue
             gap = abs(kk[0]["avg_ms"] / avg_ms - 1.0)
-            if best_gap is None or gap < best_gap:
-                best_gap, prof = gap, dict(tj, _file=f"profiles/{tf.name}")
+            # the NEWEST profile (rNN_final after rNN_base / rNN_mid, a later round after an earlier one) whose kernel time agrees with
+            # this run's within 5 %; an older one only if no newer one agrees -- equal times do not make an old code's counters current
+            rank = (tf.name.split("_")[0], {"base": 0, "mid": 1}.get(tf.name.split("_")[1], 2), tf.name)
+            if gap <= 0.05 and (best_gap is None or rank > best_gap):
+                best_gap, prof = rank, dict(tj, _file=f"profiles/{tf.name}")
 
     def prof_kernel(prefix):
         if prof is None:
