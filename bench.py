@@ -325,7 +325,7 @@ def main():
     # only while the kernel's average duration in that profile agrees with this run's within 5 % (a stale profile is not evidence).
     prof = None
     if default_workload and world == 1:  # of the committed profiles, the newest one whose dominant-kernel time agrees with this run's
-        best_gap = None
+        newest = None
         for tf in sorted((ROOT / "profiles").glob("r*_traffic.json")):
             tj = json.loads(tf.read_text())
             kk = [v for k, v in tj["kernels"].items() if k.startswith(f"rt3::{dom_name}<false") and v.get("avg_ms")]
@@ -334,9 +334,9 @@ def main():
             gap = abs(kk[0]["avg_ms"] / avg_ms - 1.0)
             # the NEWEST profile (rNN_final after rNN_base / rNN_mid, a later round after an earlier one) whose kernel time agrees with
             # this run's within 5 %; an older one only if no newer one agrees -- equal times do not make an old code's counters current
-            rank = (tf.name.split("_")[0], {"base": 0, "mid": 1}.get(tf.name.split("_")[1], 2), tf.name)
-            if gap <= 0.05 and (best_gap is None or rank > best_gap):
-                best_gap, prof = rank, dict(tj, _file=f"profiles/{tf.name}")
+            age = (tf.name.split("_")[0], {"base": 0, "mid": 1}.get(tf.name.split("_")[1], 2), tf.name)
+            if gap <= 0.05 and (newest is None or age > newest):
+                newest, prof = age, dict(tj, _file=f"profiles/{tf.name}")
 
     def prof_kernel(prefix):
         if prof is None:

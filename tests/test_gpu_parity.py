@@ -711,6 +711,32 @@ def test_bench_falls_back_when_the_communicator_cannot_be_built():
     assert "rt3_comm_init failed" in r.stderr
 
 
+def test_bench_default_command_prints_the_contract_line():
+    """`python bench.py` exactly as the driver runs it at N = 1 (default workload: the branch that looks up the committed counter
+    profiles), shortened only in steps and the CPU leg: ONE JSON line with the contract's keys, a roofline whose fraction is one,
+    and per-kernel times that add up to the step."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RT3_DIST_BACKEND", "RT3_SKY_W")}
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    js = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(js) == 1, r.stdout[-2000:]
+    d = json.loads(js[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["config"]["workload"].startswith("C3")
+    rf = d["roofline"]
+    assert rf["unit"] == "GB/s" and 0.0 < rf["frac"] <= 1.0 and rf["achieved"] <= rf["peak"]
+    ms = rf["ms_per_frame"]
+    assert abs(sum(ms.values()) - d["ms_per_step"]) < 0.05 * d["ms_per_step"]
+
+
 def test_bench_refuses_more_ranks_than_devices():
     """The same command on the real backend (RCCL cannot put two ranks on one GPU): with fewer than N visible devices it must exit
     non-zero with a message, never report a 1-GPU number as the N-GPU point."""
