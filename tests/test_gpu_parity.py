@@ -200,6 +200,51 @@ def test_lbvh_edge_cases():
     ctx.close()
 
 
+def _random_soup(n, seed, kind):
+    """n triangles: 'cloud' = uniform small triangles, 'grid' = a regular lattice (equal SAH costs, coincident centroids along axes),
+    'dups' = a few distinct triangles repeated many times (identical Morton codes, ties everywhere), 'slivers' = long thin ones."""
+    rng = np.random.default_rng(seed)
+    if kind == "grid":
+        side = int(np.ceil(np.sqrt(n)))
+        ij = np.stack(np.meshgrid(np.arange(side), np.arange(side), indexing="ij"), -1).reshape(-1, 2)[:n].astype(np.float32)
+        base = np.concatenate([ij, np.zeros((n, 1), np.float32)], 1)
+        v = np.stack([base, base + [0.9, 0, 0], base + [0, 0.9, 0]], 1)
+    elif kind == "dups":
+        proto = rng.uniform(-1, 1, (max(2, n // 40), 3, 3)).astype(np.float32)
+        v = proto[rng.integers(0, len(proto), n)]
+    elif kind == "slivers":
+        c = rng.uniform(-4, 4, (n, 1, 3))
+        d = rng.normal(size=(n, 1, 3)) * [8.0, 0.05, 0.05]
+        v = (c + np.concatenate([np.zeros((n, 1, 3)), d, rng.normal(size=(n, 1, 3)) * 0.05], 1)).astype(np.float32)
+    else:
+        c = rng.uniform(-4, 4, (n, 1, 3))
+        v = (c + rng.normal(size=(n, 3, 3)) * 0.2).astype(np.float32)
+    mb = assets.MeshBuilder()
+    verts = v.reshape(-1, 3)
+    mb.add("soup", verts, np.tile([0, 0, 1], (len(verts), 1)), None, np.arange(3 * n, dtype=np.uint32).reshape(n, 3), assets.Material())
+    return mb.build()
+
+
+@pytest.mark.parametrize("kind", ["cloud", "grid", "dups", "slivers"])
+def test_lbvh_random_soups_bit_identical(kind):
+    """The builder against the oracle's on triangle soups sized around every hand-over of the device SAH top (one 16-lane group up to
+    16 clusters, one workgroup up to 4096, tiles beyond) and with the inputs that make its choices hard: lattices (equal costs, so the
+    first minimum in (axis, plane) order decides), repeated triangles (identical Morton codes, coincident centroids -> halved in
+    index order), slivers (boxes that overlap everything)."""
+    ctx = Context(0)
+    for n, T in ((3, 2), (4, 2), (5, 1), (17, 1), (33, 2), (34, 1), (35, 2), (64, 2), (130, 1), (513, 2), (1000, 3), (4097, 1), (8200, 1), (8300, 2), (20000, 1)):
+        mesh = _random_soup(n, 1000 + n, kind)
+        osc = orc.Scene(mesh, sah_top=T, leaf_size=min(2, T) if T > 1 else 1)
+        ctx.set_option(L.OPT_SAH_TOP, T)
+        ctx.set_option(L.OPT_LEAF_SIZE, min(2, T) if T > 1 else 1)
+        ctx.upload_mesh(mesh)
+        ctx.build_accel()
+        assert ctx.accel_info()[:3] == (osc.n_nodes, osc.n_tris, osc.max_depth), (kind, n, T)
+        nodes, tris = ctx.accel_download()
+        assert np.array_equal(tris, osc.tris()) and np.array_equal(nodes, osc.nodes()), (kind, n, T)
+    ctx.close()
+
+
 def test_trace_closest_and_any_exact(small):
     mesh, sky, bn, osc = small
     ctx = Context(0)
