@@ -411,7 +411,7 @@ def main():
                    "tris_per_ray": round(cst.shadow_tris_tested / max(cst.shadow_rays, 1), 2)},
         "all_traversal": {"algorithmic_GBps": round((ext_bytes + sh_bytes) / max(trav_ms * 1e-3, 1e-12) / 1e9, 1), "ms_per_frame": round(trav_ms, 3),
                           "launches_per_frame": (st.trace_launches + st.extend_launches + st.shadow_launches) / steps},
-        "k_shade": {"bound": "hbm", "streaming_bytes_per_frame": round(shade_stream), "achieved": round(shade_gbps, 1), "peak": peak, "unit": "GB/s",
+        "k_shade": {"bound": "dependent-gather latency at 6 waves per SIMD + fabric traffic (DESIGN.md 7: a sky 16 x smaller, i.e. cache resident, saves 0.6 ms of 24); hbm share in hbm_side_frac", "streaming_bytes_per_frame": round(shade_stream), "achieved": round(shade_gbps, 1), "peak": peak, "unit": "GB/s",
                     "frac": round(shade_gbps / peak, 4), "traffic_per_frame": round(shade_traffic) if shade_traffic else None,
                     "hbm_side_frac": round(shade_traffic / (shade_ms * 1e-3) / 1e9 / peak, 4) if shade_traffic else None,
                     "traffic_over_streaming": round(shade_traffic / shade_stream, 2) if shade_traffic else None},
