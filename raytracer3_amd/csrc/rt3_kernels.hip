@@ -143,7 +143,9 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
     // the first chunk of every wave is static (chunk number = global wave number): no atomic storm at launch, when all the
     // waves of the grid would hit the cursor at once (8192 returning atomics on one word ~ 0.1 ms); the cursor counts the
     // chunks handed out after those
-    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6), wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+    // (wave-uniform, but only the hardware knows: without the readfirstlane the pool cursors live in vector registers)
+    const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     bool first_chunk = true;
     uint32_t spill[kSpill];
     LaneRay r;
@@ -217,12 +219,10 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
             const uint32_t taken = (uint32_t)__popcll(m_idle);
             pool_next = pool_next + taken < pool_end ? pool_next + taken : pool_end;
         }
-        if (__ballot(busy) == 0ull) {
-            if (pool_next >= pool_end && queue_empty) break;
-            continue;
-        }
-        if (!busy) continue;
-        // ---- one traversal step
+        if (__ballot(busy) == 0ull && pool_next >= pool_end && queue_empty) break;
+        // ---- one traversal step.  (One region under `if (busy)` and a single way back to the loop header: with `continue`s in front of it
+        // the compiler copied the eight registers of the walk's state aside at the top of every step and back at its end.)
+        if (busy) {
         const bool ANY = MODE == 2 ? lane_any : MODE == 1;  // compile-time constant for MODE 0 / 1, per lane for MODE 2
         const bool is_leaf = (r.cur & 0x80000000u) != 0u;
         const uint32_t first = r.cur & 0x0FFFFFFFu, cnt = ((r.cur >> 28) & 7u) + 1u;
@@ -398,6 +398,7 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
             finish(r.index, r.best, r.cn, r.ct, MODE == 2 ? lane_any : MODE == 1, r.pay0, r.pay1);
             busy = false;
         }
+        }  // if (busy)
     }
 }
 
