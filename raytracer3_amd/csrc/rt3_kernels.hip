@@ -108,7 +108,8 @@ struct LaneRay {  // traversal state of the ray a lane currently owns
     Hit best;
     uint32_t cur, leaf_k, index, steps, cn, ct;
     int sp;
-    float pay0, pay1;  // shadow rays of the path tracer's own queue: two words of payload ride in the .w of the two ray records
+    float pay0, pay1;  // shadow rays of the path tracer's own queue: two words of payload ride in the .w of the two ray records,
+    float pay2, pay3;  // two more ({blue, path id}) in an 8-byte record fetched WITH the ray: at the end of the walk nothing is left to wait for
 };
 
 // MODE 0: closest hit over one queue; 1: any hit over one queue; 2: both queues in one walk -- the lanes of a wave take
@@ -119,7 +120,8 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
                                              const float* __restrict__ rays_a, size_t stride, uint32_t n_a, uint32_t* __restrict__ work_counter_a,
                                              uint32_t* __restrict__ lds, Finish finish, bool any_payload = false,
                                              const float* __restrict__ rays_b = nullptr, uint32_t n_b = 0, uint32_t* __restrict__ work_counter_b = nullptr,
-                                             bool ext_payload = false, const float4* top_lds = nullptr, bool use_top = false) {
+                                             bool ext_payload = false, const float4* top_lds = nullptr, bool use_top = false,
+                                             const float2* __restrict__ any_contrib = nullptr) {
     // any_payload: the any-hit rays come from k_shade's shadow queue, where every ray has the range (kRayTMin, kBackgroundDepth):
     // the two .w slots of its record carry payload (two contribution channels) instead of tmin / tmax -- 16 bytes less per ray.
     // ext_payload: likewise for the extension rays of the path tracer's own queue (.w = the path's pdf and id, read by k_shade)
@@ -155,7 +157,7 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
     r.best = Hit{0.0f, 0.0f, 0.0f, kMiss};
     r.cur = r.leaf_k = r.index = r.steps = r.cn = r.ct = 0u;
     r.sp = 0;
-    r.pay0 = r.pay1 = 0.0f;
+    r.pay0 = r.pay1 = r.pay2 = r.pay3 = 0.0f;
     bool busy = false;
     for (;;) {
         // ---- refill idle lanes from the pool
@@ -196,6 +198,11 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
                 r.best = Hit{payload ? kBackgroundDepth : rd.w, 0.0f, 0.0f, kMiss};
                 r.pay0 = ro.w;
                 r.pay1 = rd.w;
+                if (any_contrib != nullptr && (MODE == 1 || (MODE == 2 && second_pool))) {
+                    const float2 c2 = any_contrib[idx];
+                    r.pay2 = c2.x;
+                    r.pay3 = c2.y;
+                }
                 r.inv = v3(guarded_inverse(r.d.x), guarded_inverse(r.d.y), guarded_inverse(r.d.z));
                 r.inv_dd = 1.0f / dot_fma(r.d, r.d);
                 r.cur = (LAYOUT == kLayoutWide64Q && use_top) ? kTopFlag : 0u;  // the root: slot 0 of the LDS copy, or node 0
@@ -212,7 +219,7 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
                 const bool finite_ray = fabsf(r.o.x) <= kMaxF && fabsf(r.o.y) <= kMaxF && fabsf(r.o.z) <= kMaxF && fabsf(r.d.x) <= kMaxF &&
                                         fabsf(r.d.y) <= kMaxF && fabsf(r.d.z) <= kMaxF;
                 if (nodes == nullptr || !finite_ray) {  // empty scene: everything misses
-                    finish(r.index, r.best, 0u, 0u, MODE == 2 ? lane_any : MODE == 1, r.pay0, r.pay1);
+                    finish(r.index, r.best, 0u, 0u, MODE == 2 ? lane_any : MODE == 1, r.pay0, r.pay1, r.pay2, r.pay3);
                     busy = false;
                 }
             }
@@ -395,7 +402,7 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
         // kMaxSteps bounds the walk so that a corrupt tree can never hang the GPU (a valid tree visits < 2 n nodes)
         if (++r.steps >= kMaxSteps) done = true;
         if (done) {
-            finish(r.index, r.best, r.cn, r.ct, MODE == 2 ? lane_any : MODE == 1, r.pay0, r.pay1);
+            finish(r.index, r.best, r.cn, r.ct, MODE == 2 ? lane_any : MODE == 1, r.pay0, r.pay1, r.pay2, r.pay3);
             busy = false;
         }
         }  // if (busy)
@@ -416,7 +423,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(const float4* __restric
     const bool use_top = load_top(s_top, top, n_top);  // (the LDS array itself is passed on, never a selected pointer: a select would turn its reads into flat loads)
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
     unsigned long long tot_n = 0, tot_t = 0;
-    auto finish = [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, bool, float, float) {
+    auto finish = [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, bool, float, float, float, float) {
         // one 16-byte record per ray: with persistent waves rays finish out of order, four SoA streams would be four
         // scattered partial-line writes
         reinterpret_cast<float4*>(hits)[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
@@ -452,14 +459,15 @@ __global__ __launch_bounds__(kExtendBlock) void k_shadow(const float4* __restric
     unsigned long long tot_n = 0, tot_t = 0;
     trace_stream<1, COUNT, LAYOUT>(
         nodes, tris, rays, stride, n, work_counter, stack + threadIdx.x,
-        [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, bool, float c_r, float c_g) {
+        [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, bool, float c_r, float c_g, float c_b, float c_pid) {
             if (occluded_out) {
                 occluded_out[i] = h.prim != kMiss ? 1u : 0u;
             } else if (h.prim == kMiss) {
-                const float2 c = reinterpret_cast<const float2*>(contrib)[i];  // {blue, path id}; red and green rode with the ray
-                float4* L = reinterpret_cast<float4*>(lacc) + __float_as_uint(c.y);  // one 16-byte read-modify-write per path
+                // red and green rode with the ray, {blue, path id} arrived with it: one 16-byte read-modify-write per path, and the
+                // wave waits for ONE round trip here (it used to be two: the id first, the slot after)
+                float4* L = reinterpret_cast<float4*>(lacc) + __float_as_uint(c_pid);
                 float4 v = *L;
-                *L = make_float4(v.x + c_r, v.y + c_g, v.z + c.x, 0.0f);
+                *L = make_float4(v.x + c_r, v.y + c_g, v.z + c_b, 0.0f);
             }
             if (COUNT) {
                 if (cnt_nodes) cnt_nodes[i] = cn;
@@ -468,7 +476,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_shadow(const float4* __restric
                 tot_t += ct;
             }
         },
-        occluded_out == nullptr, nullptr, 0, nullptr, false, s_top, use_top);
+        occluded_out == nullptr, nullptr, 0, nullptr, false, s_top, use_top, occluded_out == nullptr ? reinterpret_cast<const float2*>(contrib) : nullptr);
     if (COUNT && totals) {
         atomicAdd(&totals[0], tot_n);
         atomicAdd(&totals[1], tot_t);
@@ -493,14 +501,13 @@ __global__ __launch_bounds__(kExtendBlock) void k_trace(const float4* __restrict
     unsigned long long en = 0, et = 0, sn = 0, stt = 0;
     trace_stream<2, COUNT, LAYOUT>(
         nodes, tris, ext_rays, stride, n_ext, work_ext, stack + threadIdx.x,
-        [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, bool any, float c_r, float c_g) {
+        [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, bool any, float c_r, float c_g, float c_b, float c_pid) {
             if (!any) {
                 reinterpret_cast<float4*>(hits)[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
             } else if (h.prim == kMiss) {
-                const float2 c = reinterpret_cast<const float2*>(contrib)[i];  // {blue, path id}
-                float4* L = reinterpret_cast<float4*>(lacc) + __float_as_uint(c.y);
+                float4* L = reinterpret_cast<float4*>(lacc) + __float_as_uint(c_pid);  // {blue, path id} came with the ray
                 float4 v = *L;
-                *L = make_float4(v.x + c_r, v.y + c_g, v.z + c.x, 0.0f);
+                *L = make_float4(v.x + c_r, v.y + c_g, v.z + c_b, 0.0f);
             }
             if (COUNT) {
                 en += any ? 0u : cn;
@@ -509,7 +516,7 @@ __global__ __launch_bounds__(kExtendBlock) void k_trace(const float4* __restrict
                 stt += any ? ct : 0u;
             }
         },
-        true, sh_rays, n_sh, work_sh, true, s_top, use_top);
+        true, sh_rays, n_sh, work_sh, true, s_top, use_top, reinterpret_cast<const float2*>(contrib));
     if (COUNT && totals) {
         if (blockIdx.x == 0 && threadIdx.x == 0) {
             atomicAdd(&totals[0], (unsigned long long)n_ext);
