@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--fused-trace", type=int, default=-1, help="RT3_OPT_FUSED_TRACE: 1 one k_trace launch per bounce, 0 separate k_shadow / k_extend, -1 library default")
     ap.add_argument("--sah-top", type=int, default=-1, help="RT3_OPT_SAH_TOP: cluster size T of the SAH top (0 = plain LBVH, -1 = library default)")
     ap.add_argument("--pool-chunk", type=int, default=0, help="traversal tuning: rays per pool grab (RT3_OPT_POOL_CHUNK)")
+    ap.add_argument("--trace-blocks", type=int, default=0, help="traversal tuning: persistent workgroups per traversal launch (RT3_OPT_TRACE_BLOCKS)")
     ap.add_argument("--flags", type=int, default=-1, help="GConst.pad[0] feature flags (-1 = the full estimator); experiments only")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-crop", type=str, default="1280x720")  # ~14 s of oracle time on the GPU box's 16 host cores
@@ -164,7 +165,7 @@ def main():
         sys.exit(self_launch(args.gpus, sys.argv[1:]))
     default_workload = ((args.width, args.height, args.spp, args.bounces, args.detail) == (1920, 1080, 64, 4, 1.0)
                         and args.batch_spp == 0 and args.leaf_size == 0 and args.node_width == 0 and args.node_quant == -1
-                        and args.refill == -1 and args.flags == -1 and args.pool_chunk == 0 and args.fused_trace == -1 and args.sah_top == -1)
+                        and args.refill == -1 and args.flags == -1 and args.pool_chunk == 0 and args.trace_blocks == 0 and args.fused_trace == -1 and args.sah_top == -1)
 
     import numpy as np
     import torch
@@ -215,6 +216,8 @@ def main():
         pt.ctx.set_option(L.OPT_EXTEND_VARIANT, args.refill)
     if args.pool_chunk:
         pt.ctx.set_option(L.OPT_POOL_CHUNK, args.pool_chunk)
+    if args.trace_blocks:
+        pt.ctx.set_option(L.OPT_TRACE_BLOCKS, args.trace_blocks)
     if args.sah_top >= 0:
         pt.ctx.set_option(L.OPT_SAH_TOP, args.sah_top)
     if args.fused_trace >= 0:
