@@ -102,6 +102,18 @@ __device__ __forceinline__ bool load_top(float4* s_top, const float4* __restrict
     return true;
 }
 
+// slab test of a quantised child whose plane bytes arrive near-first: p = {near.x, near.y, near.z, far.x}, q = {far.y, far.z, -, -}
+// (v_perm_b32 by the ray's sign selectors).  The same maxima / minima as slab_test_q, minus the six that ordered each axis' pair.
+__device__ __forceinline__ bool slab_test_sorted(uint32_t p, uint32_t q, V3 A, V3 B, float tmin, float tbest, float& tn_out) {
+    const float nx = __builtin_fmaf((float)(p & 0xFFu), A.x, B.x), ny = __builtin_fmaf((float)((p >> 8) & 0xFFu), A.y, B.y),
+                nz = __builtin_fmaf((float)((p >> 16) & 0xFFu), A.z, B.z), fx = __builtin_fmaf((float)(p >> 24), A.x, B.x),
+                fy = __builtin_fmaf((float)(q & 0xFFu), A.y, B.y), fz = __builtin_fmaf((float)((q >> 8) & 0xFFu), A.z, B.z);
+    const float tn = __builtin_fmaxf(__builtin_fmaxf(nx, ny), __builtin_fmaxf(nz, tmin));
+    const float tf = __builtin_fminf(__builtin_fminf(fx, fy), __builtin_fminf(fz, tbest));
+    tn_out = tn;
+    return tn <= tf;
+}
+
 struct LaneRay {  // traversal state of the ray a lane currently owns
     V3 o, d, inv;
     float tmin, inv_dd;  // inv_dd = 1 / d.d (the triangle test makes no unit-length assumption)
@@ -110,6 +122,7 @@ struct LaneRay {  // traversal state of the ray a lane currently owns
     int sp;
     float pay0, pay1;  // shadow rays of the path tracer's own queue: two words of payload ride in the .w of the two ray records,
     float pay2, pay3;  // two more ({blue, path id}) in an 8-byte record fetched WITH the ray: at the end of the walk nothing is left to wait for
+    uint32_t sel_p0, sel_q0, sel_p1, sel_q1;  // default layout: v_perm_b32 selectors that put a child's NEAR planes first (see the box block)
 };
 
 // MODE 0: closest hit over one queue; 1: any hit over one queue; 2: both queues in one walk -- the lanes of a wave take
@@ -161,6 +174,7 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
     r.cur = r.leaf_k = r.index = r.steps = r.cn = r.ct = 0u;
     r.sp = 0;
     r.pay0 = r.pay1 = r.pay2 = r.pay3 = 0.0f;
+    r.sel_p0 = r.sel_q0 = r.sel_p1 = r.sel_q1 = 0u;
     bool busy = false;
     for (;;) {
         // ---- refill idle lanes from the pool
@@ -208,6 +222,19 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
                 }
                 r.inv = v3(guarded_inverse(r.d.x), guarded_inverse(r.d.y), guarded_inverse(r.d.z));
                 r.inv_dd = 1.0f / dot_fma(r.d, r.d);
+                if (LAYOUT == kLayoutWide64Q) {
+                    // A child's six plane bytes are {lo.xyz, hi.xyz} at bytes 0..5 (children 0, 2) or 2..7 (children 1, 3) of a word pair.
+                    // Which of lo / hi is the NEAR plane of an axis is the sign of the ray's direction there, the same for every node:
+                    // two v_perm_b32 per child pull {near.x, near.y, near.z, far.x} and {far.y, far.z} out, and the six min / max that
+                    // ordered each pair are gone.  Same values: fma(q, A, B) is monotone in q, increasing for A >= 0, decreasing below,
+                    // and no operand can be NaN (positions are bounded at upload, rays are checked finite, inverses are guarded).
+                    const uint32_t sx = r.inv.x < 0.0f ? 1u : 0u, sy = r.inv.y < 0.0f ? 1u : 0u, sz = r.inv.z < 0.0f ? 1u : 0u;
+                    const uint32_t nx = 3u * sx, ny = 1u + 3u * sy, nz = 2u + 3u * sz, fx = 3u - 3u * sx, fy = 4u - 3u * sy, fz = 5u - 3u * sz;
+                    r.sel_p0 = nx | (ny << 8) | (nz << 16) | (fx << 24);
+                    r.sel_q0 = fy | (fz << 8);
+                    r.sel_p1 = r.sel_p0 + 0x02020202u;
+                    r.sel_q1 = r.sel_q0 + 0x00000202u;
+                }
                 r.cur = (LAYOUT == kLayoutWide64Q && use_top) ? kTopFlag : 0u;  // the root: slot 0 of the LDS copy, or node 0
                 r.leaf_k = 0u;
                 r.sp = 0;
@@ -326,10 +353,20 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
 #define RT3_SLABQ(lx, ly, lz, hx, hy, hz, tn) \
     slab_test_q(__builtin_fmaf(lx, A.x, B.x), __builtin_fmaf(hx, A.x, B.x), __builtin_fmaf(ly, A.y, B.y), __builtin_fmaf(hy, A.y, B.y), \
                 __builtin_fmaf(lz, A.z, B.z), __builtin_fmaf(hz, A.z, B.z), tmin, r.best.t, tn)
+                    if (LAYOUT == kLayoutWide64Q) {
+#define RT3_SLABS(wlo, whi, selp, selq, tn)                                                                                                    \
+    slab_test_sorted(__builtin_amdgcn_perm(whi, wlo, selp), __builtin_amdgcn_perm(whi, wlo, selq), A, B, tmin, r.best.t, tn)
+                        h0 = RT3_SLABS(w0, w1, r.sel_p0, r.sel_q0, t0) & (r0 != kEmptySlot);
+                        h1 = RT3_SLABS(w1, w2, r.sel_p1, r.sel_q1, t1) & (r1 != kEmptySlot);
+                        h2 = RT3_SLABS(w3, w4, r.sel_p0, r.sel_q0, t2) & (r2 != kEmptySlot);
+                        h3 = RT3_SLABS(w4, w5, r.sel_p1, r.sel_q1, t3) & (r3 != kEmptySlot);
+#undef RT3_SLABS
+                    } else {
                     h0 = RT3_SLABQ(RT3_Q(w0, 0), RT3_Q(w0, 1), RT3_Q(w0, 2), RT3_Q(w0, 3), RT3_Q(w1, 0), RT3_Q(w1, 1), t0) & (r0 != kEmptySlot);
                     h1 = RT3_SLABQ(RT3_Q(w1, 2), RT3_Q(w1, 3), RT3_Q(w2, 0), RT3_Q(w2, 1), RT3_Q(w2, 2), RT3_Q(w2, 3), t1) & (r1 != kEmptySlot);
                     h2 = RT3_SLABQ(RT3_Q(w3, 0), RT3_Q(w3, 1), RT3_Q(w3, 2), RT3_Q(w3, 3), RT3_Q(w4, 0), RT3_Q(w4, 1), t2) & (r2 != kEmptySlot);
                     h3 = RT3_SLABQ(RT3_Q(w4, 2), RT3_Q(w4, 3), RT3_Q(w5, 0), RT3_Q(w5, 1), RT3_Q(w5, 2), RT3_Q(w5, 3), t3) & (r3 != kEmptySlot);
+                    }
 #undef RT3_Q
 #undef RT3_SLABQ
                 } else {
