@@ -446,11 +446,12 @@ uint32_t orc_accel_node_words(const orc_scene *s) { return s->node_width == 2 ? 
  *   words 0-2  origin = min corner of the union of the child boxes
  *   word  3    biased exponents ex | ey << 8 | ez << 16 of the per-axis power-of-two grid step (scale = 2^(e-127))
  *   words 4-9  24 bytes: child k at bytes 6k..6k+5 = qlo.xyz, qhi.xyz (8 bit each)
- *   words 10-13 the four child references, words 14-15 zero
+ *   words 10-13 the four child references; words 14-15 zero -- or, in the 64-byte node, the y and z steps as floats (word 3 then holds
+ *   the x step as a float instead of the three exponent bytes)
  * decode: lo = origin + float(qlo) * scale, hi = origin + float(qhi) * scale.  Quantisation is conservative with
  * respect to exactly that decode expression (lo' <= lo, hi' >= hi), so no hit can be lost; empty slots keep ref
  * 0xFFFFFFFF and are skipped by reference. */
-static void quantize_node(const float mn[4][3], const float mx[4][3], const uint32_t ref[4], uint32_t ns, uint32_t out[16]) {
+static void quantize_node(const float mn[4][3], const float mx[4][3], const uint32_t ref[4], uint32_t ns, int float_steps, uint32_t out[16]) {
     float org[3]; uint32_t eb[3]; uint8_t q[4][6];
     memset(q, 0, sizeof(q));
     for (int a = 0; a < 3; a++) {
@@ -485,6 +486,9 @@ static void quantize_node(const float mn[4][3], const float mx[4][3], const uint
     uint8_t *bytes = (uint8_t *)(out + 4);
     for (uint32_t k = 0; k < 4; k++) for (int j = 0; j < 6; j++) bytes[6 * k + j] = k < ns ? q[k][j] : (j < 3 ? 255 : 0);
     for (uint32_t k = 0; k < 4; k++) out[10 + k] = k < ns ? ref[k] : 0xFFFFFFFFu;
+    if (float_steps) { /* the 64-byte node: the three steps as floats in word 3 and the spare words 14, 15 (the kernels multiply them as they are) */
+        out[3] = eb[0] << 23; out[14] = eb[1] << 23; out[15] = eb[2] << 23;
+    }
 }
 /* Compact 48-byte node (node_quant 2): words 0..9 as above, but the four references are implied.  The internal children of
  * a node are numbered consecutively from node_base and the triangles of its leaf children are stored consecutively from
@@ -494,7 +498,7 @@ static void quantize_node(const float mn[4][3], const float mx[4][3], const uint
 static void compact_node(const float mn[4][3], const float mx[4][3], const uint32_t meta[4], uint32_t ns, uint32_t node_base,
                          uint32_t tri_base, uint32_t out[12]) {
     uint32_t tmp[16], ref[4] = {0, 0, 0, 0};
-    quantize_node(mn, mx, ref, ns, tmp);
+    quantize_node(mn, mx, ref, ns, 0, tmp);
     memcpy(out, tmp, 40);
     uint32_t m[4];
     for (uint32_t k = 0; k < 4; k++) m[k] = k < ns ? meta[k] : 7u;
@@ -515,7 +519,7 @@ static void compact_refs(const uint32_t *nd, uint32_t ref[4]) {
 __attribute__((unused)) static void dequantize_slot(const uint32_t *nd, int k, float box[6]) {
     const uint8_t *bytes = (const uint8_t *)(nd + 4);
     for (int a = 0; a < 3; a++) {
-        float scale = u2f(((nd[3] >> (8 * a)) & 0xFFu) << 23), org = u2f(nd[a]);
+        float scale = u2f(a == 0 ? nd[3] : nd[13 + a]), org = u2f(nd[a]); /* (64-byte node; the 48-byte one keeps exponent bytes in word 3) */
         box[a] = org + (float)bytes[6 * k + a] * scale;
         box[3 + a] = org + (float)bytes[6 * k + 3 + a] * scale;
     }
@@ -895,7 +899,7 @@ int orc_accel_build(orc_scene *s) {
             float qmn[4][3], qmx[4][3]; uint32_t qref[4] = {0x80000000u, 0, 0, 0}, qmeta[4] = {8u, 7u, 7u, 7u};
             memcpy(qmn[0], lmin, 12); memcpy(qmx[0], lmax, 12);
             if (s->node_quant == 2) compact_node(qmn, qmx, qmeta, 1, 1u, 0u, (uint32_t *)nd);
-            else quantize_node(qmn, qmx, qref, 1, (uint32_t *)nd);
+            else quantize_node(qmn, qmx, qref, 1, 1, (uint32_t *)nd);
         } else
         for (uint32_t k = 0; k < (W4 ? 4u : 2u); k++) {
             float *mn = W4 ? nd + 8 * k : nd + 6 * k, *mx = mn + 3;
@@ -1047,7 +1051,7 @@ int orc_accel_build(orc_scene *s) {
                 else { memcpy(nd + 6 * k, mn, 12); memcpy(nd + 6 * k + 3, mx, 12); nd[12 + k] = u2f(ref); }
             }
             if (QN == 2) compact_node(qmn, qmx, qmeta, ns, 1u + cbase[i], tbase[i], (uint32_t *)nd);
-            else if (QN) quantize_node(qmn, qmx, qref, ns, (uint32_t *)nd);
+            else if (QN) quantize_node(qmn, qmx, qref, ns, 1, (uint32_t *)nd);
             uint32_t lvl = wlevel[i] + 2u; /* levels from the root to this node's leaf slots */
             if (lvl > maxd) maxd = lvl;
         }
@@ -1197,7 +1201,7 @@ static void traverse(const orc_scene *s, const float o[3], const float d[3], flo
                 if (QN == 2) compact_refs((const uint32_t *)nd, r48);
                 if (QN) for (int a = 0; a < 3; a++) {
                     const uint32_t *w = (const uint32_t *)nd;
-                    float step = u2f(((w[3] >> (8 * a)) & 0xFFu) << 23);
+                    float step = QN == 2 ? u2f(((w[3] >> (8 * a)) & 0xFFu) << 23) : u2f(a == 0 ? w[3] : w[13 + a]); /* exponent bytes (48 B) / floats (64 B) */
                     A[a] = step * inv[a];
                     B[a] = (nd[a] - o[a]) * inv[a];
                 }

@@ -321,8 +321,10 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
                     // q * (step * inv) + (org - o) * inv = fma(q, A, B): one v_cvt_f32_ubyte + one v_fma_f32 per plane.
                     // Bytes 6k..6k+5 of words 4..9 hold child k {lo.xyz, hi.xyz}.
                     const uint32_t ex = __float_as_uint(q0.w);
-                    const V3 A = v3(__uint_as_float((ex & 0xFFu) << 23) * inv.x, __uint_as_float(((ex >> 8) & 0xFFu) << 23) * inv.y,
-                                    __uint_as_float(((ex >> 16) & 0xFFu) << 23) * inv.z);
+                    // (the 64-byte node holds its steps as floats -- word 3, words 14 / 15; the 48-byte one as three exponent bytes)
+                    const V3 A = C48 ? v3(__uint_as_float((ex & 0xFFu) << 23) * inv.x, __uint_as_float(((ex >> 8) & 0xFFu) << 23) * inv.y,
+                                          __uint_as_float(((ex >> 16) & 0xFFu) << 23) * inv.z)
+                                     : v3(q0.w * inv.x, q3.z * inv.y, q3.w * inv.z);
                     const V3 B = v3((q0.x - o.x) * inv.x, (q0.y - o.y) * inv.y, (q0.z - o.z) * inv.z);
                     const uint32_t w0 = __float_as_uint(q1.x), w1 = __float_as_uint(q1.y), w2 = __float_as_uint(q1.z), w3 = __float_as_uint(q1.w),
                                    w4 = __float_as_uint(q2.x), w5 = __float_as_uint(q2.y);

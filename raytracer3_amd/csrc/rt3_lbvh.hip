@@ -326,7 +326,8 @@ __device__ __forceinline__ void slot_of(uint32_t ch, const float* lmin, const fl
 }
 
 // 64-byte four-wide node with 8-bit child boxes on a per-axis power-of-two grid anchored at the node's min corner:
-//   float4 0: origin.xyz, exponents ex | ey << 8 | ez << 16      float4 1 + first half of 2: 4 x {qlo.xyz, qhi.xyz} bytes
+//   float4 0: origin.xyz, exponents ex | ey << 8 | ez << 16 (quantize_words; quantize_node turns them into three float steps: word 3, words 14 / 15)
+//   float4 1 + first half of 2: 4 x {qlo.xyz, qhi.xyz} bytes
 //   float4 2 second half + float4 3 first half: the four references
 // Conservative with respect to the decode expression origin + float(q) * scale used by the traversal kernels.
 __device__ void quantize_words(const float (*mn)[3], const float (*mx)[3], const uint32_t* ref, uint32_t ns, uint32_t* w) {
@@ -375,6 +376,12 @@ __device__ void quantize_words(const float (*mn)[3], const float (*mx)[3], const
 __device__ void quantize_node(const float (*mn)[3], const float (*mx)[3], const uint32_t* ref, uint32_t ns, float4* out) {
     uint32_t w[16];
     quantize_words(mn, mx, ref, ns, w);
+    // the 64-byte node carries its three steps as FLOATS (word 3 and the two spare words 14, 15): the walk multiplies them into the
+    // ray's inverse direction at every node and used to rebuild each from its exponent byte first (a shift and a mask per axis)
+    const uint32_t ex = w[3];
+    w[3] = (ex & 0xFFu) << 23;
+    w[14] = ((ex >> 8) & 0xFFu) << 23;
+    w[15] = ((ex >> 16) & 0xFFu) << 23;
 #pragma unroll
     for (int k = 0; k < 4; k++)
         out[k] = make_float4(__uint_as_float(w[4 * k]), __uint_as_float(w[4 * k + 1]), __uint_as_float(w[4 * k + 2]), __uint_as_float(w[4 * k + 3]));
