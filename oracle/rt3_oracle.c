@@ -403,7 +403,7 @@ struct orc_scene {
     orc_geometry_info *geoms; uint32_t *prim_counts, *first_prim; uint32_t n_geoms;
     uint32_t n_prims; uint32_t *prim_geom;
     /* accel */
-    uint32_t n_tris, n_nodes, max_depth, leaf_max, node_width, node_quant, collapse, sah_top;
+    uint32_t n_tris, n_nodes, max_depth, leaf_max, node_width, node_quant, collapse, sah_top, tree_order;
     float *nodes;   /* 16 words per node */
     float *tris;    /* 12 words per tri (Morton order) */
     uint64_t *codes;
@@ -438,7 +438,8 @@ void orc_accel_set_layout(orc_scene *s, uint32_t leaf_max, uint32_t node_width, 
     s->node_width = node_width == 2 ? 2 : 4;
     s->node_quant = s->node_width == 4 ? (quantized > 2 ? 2 : quantized) : 0; /* 0 fp32 128 B, 1 quantised 64 B, 2 compact 48 B */
 }
-void orc_accel_set_collapse(orc_scene *s, uint32_t mode) { s->collapse = mode ? 1u : 0u; }
+void orc_accel_set_collapse(orc_scene *s, uint32_t mode) { s->collapse = mode > 2u ? 2u : mode; }
+void orc_accel_set_tree_order(orc_scene *s, uint32_t on) { s->tree_order = on ? 1u : 0u; }
 void orc_accel_set_sah_top(orc_scene *s, uint32_t cluster_size) { s->sah_top = cluster_size; }
 uint32_t orc_accel_node_words(const orc_scene *s) { return s->node_width == 2 ? 16u : (s->node_quant == 2 ? 12u : (s->node_quant ? 16u : 32u)); }
 
@@ -836,6 +837,26 @@ static uint32_t sah_slots(uint32_t i, const uint32_t *left, const uint32_t *righ
     }
     return ns;
 }
+/* child slots of four-wide node i under the cost-driven collapse: the choices the bottom-up pass of orc_accel_build recorded in dk,
+ * unfolded top-down, left subtree's slots first */
+static uint32_t dp_slots(uint32_t i, const uint32_t *left, const uint32_t *right, const uint8_t *dk, uint32_t sl[4]) {
+    uint32_t ns = 0, sn[8], sm[8]; int sp = 0;
+    uint32_t k4 = dk[i] & 3u;
+    sn[sp] = right[i]; sm[sp++] = 4u - k4;
+    sn[sp] = left[i]; sm[sp++] = k4;
+    while (sp > 0) {
+        uint32_t nd = sn[--sp], m = sm[sp];
+        if (nd & 0x80000000u) { sl[ns++] = nd; continue; }
+        uint32_t f = dk[nd];
+        if (m == 3u && !(f & 32u)) m = 2u;
+        if (m == 2u && !(f & 16u)) m = 1u;
+        if (m == 1u) { sl[ns++] = nd; continue; }
+        uint32_t kl = m == 2u ? 1u : ((f >> 2) & 1u) + 1u;
+        sn[sp] = right[nd]; sm[sp++] = m - kl;
+        sn[sp] = left[nd]; sm[sp++] = kl;
+    }
+    return ns;
+}
 int orc_accel_build(orc_scene *s) {
     accel_free(s);
     uint32_t n = s->n_prims;
@@ -956,7 +977,7 @@ int orc_accel_build(orc_scene *s) {
                 for (int j = 0; j < 3; j++) { nmin[3 * i + j] = fminx(amn[j], bmn[j]); nmax[3 * i + j] = fmaxx(amx[j], bmx[j]); }
             }
         }
-        if (pass == 0) { if (!s->sah_top) break; sah_top_rebuild(nn, left, right, rlo, rcnt, lmin, lmax, nmin, nmax, s->sah_top > s->leaf_max ? s->sah_top : s->leaf_max); }
+        if (pass == 0) { if (!s->sah_top) break; sah_top_rebuild(nn, left, right, rlo, rcnt, lmin, lmax, nmin, nmax, (s->tree_order || (s->node_width == 4 && s->collapse == 2)) ? s->sah_top : (s->sah_top > s->leaf_max ? s->sah_top : s->leaf_max)); }
         }
         /* Multi-triangle leaves: an internal node covering <= leaf_max triangles (contiguous in Morton order) is referenced
          * as a leaf {bit 31, count-1 in bits 30..28, first triangle in bits 27..0}; the root always stays a node.
@@ -964,7 +985,74 @@ int orc_accel_build(orc_scene *s) {
          * holds 2..4 child slots {min, max, ref, pad} of 32 B = one 128 B cache line; empty slots carry ref 0xFFFFFFFF.
          * Surviving nodes are renumbered densely in index order (an exclusive scan on the GPU). */
         const uint32_t K = s->leaf_max, W4 = s->node_width == 4;
-#define ORC_LIVE(i) ((i) == 0 || rcnt[i] > K)
+        const int DP = W4 && s->collapse == 2;
+        /* [round 3] TREE ORDER: the triangle records are re-ordered into the depth-first order of the final binary tree, so that EVERY
+         * subtree (also one the SAH top re-linked) covers a contiguous range and can be referenced as a multi-triangle leaf.
+         * order[] = internal nodes in pre-order (parents first); rcnt = true triangle count, rlo = first triangle of the subtree. */
+        uint32_t *order = (uint32_t *)malloc((size_t)nn * 4), n_order = 0;
+        {
+            int sp = 0; stack[sp++] = 0;
+            while (sp > 0) {
+                uint32_t i = stack[--sp]; order[n_order++] = i;
+                if (!(right[i] & 0x80000000u)) stack[sp++] = right[i];
+                if (!(left[i] & 0x80000000u)) stack[sp++] = left[i];
+            }
+        }
+        if (s->tree_order || DP) {
+            for (uint32_t q = n_order; q-- > 0;) {
+                uint32_t i = order[q], l = left[i], r = right[i];
+                rcnt[i] = ((l & 0x80000000u) ? 1u : rcnt[l]) + ((r & 0x80000000u) ? 1u : rcnt[r]);
+            }
+            uint32_t *newpos = (uint32_t *)malloc((size_t)n * 4);
+            rlo[0] = 0;
+            for (uint32_t q = 0; q < n_order; q++) {
+                uint32_t i = order[q], l = left[i], r = right[i], f = rlo[i];
+                if (l & 0x80000000u) { newpos[l & 0x7FFFFFFFu] = f; f += 1; } else { rlo[l] = f; f += rcnt[l]; }
+                if (r & 0x80000000u) newpos[r & 0x7FFFFFFFu] = f; else rlo[r] = f;
+            }
+            float *t2 = (float *)malloc((size_t)n * 48), *mn2 = (float *)malloc((size_t)n * 12), *mx2 = (float *)malloc((size_t)n * 12);
+            for (uint32_t q = 0; q < n; q++) {
+                memcpy(t2 + 12 * (size_t)newpos[q], s->tris + 12 * (size_t)q, 48);
+                memcpy(mn2 + 3 * (size_t)newpos[q], lmin + 3 * (size_t)q, 12); memcpy(mx2 + 3 * (size_t)newpos[q], lmax + 3 * (size_t)q, 12);
+            }
+            free(s->tris); s->tris = t2; free(lmin); free(lmax); lmin = mn2; lmax = mx2;
+            for (uint32_t i = 0; i < nn; i++) {
+                if (left[i] & 0x80000000u) left[i] = 0x80000000u | newpos[left[i] & 0x7FFFFFFFu];
+                if (right[i] & 0x80000000u) right[i] = 0x80000000u | newpos[right[i] & 0x7FFFFFFFu];
+            }
+            free(newpos);
+        }
+        /* [round 3] COST-DRIVEN COLLAPSE (collapse 2; after Ylitie, Karras, Laine 2017, section 3.1): C(n, m) = the least SAH cost of
+         * representing the subtree of binary node n by at most m slots of a parent (m = 1..3),
+         *     C(n,1) = min( A_n * cnt_n * C_TRI  [a leaf, cnt_n <= leaf_max],  A_n * C_NODE + D(n,4)  [a four-wide node] )
+         *     C(n,m) = min( D(n,m), C(n,m-1) ),   D(n,j) = min over 0 < k < j of C(left,k) + C(right,j-k),   C(triangle,.) = A * C_TRI
+         * bottom-up in fp32, fixed order, strict '<' so that ties keep the earlier (fewer slots / smaller k) choice.  A node step
+         * and a triangle step of the walk cost about the same (one fetch round trip and a similar number of vector instructions),
+         * hence C_NODE = C_TRI = 1.  dk bits: 0-1 k of D(n,4); 2 k of D(n,3) minus 1; 3 C(n,1) is a leaf; 4 C(n,2) = D(n,2); 5 C(n,3) = D(n,3). */
+        float *dc = NULL; uint8_t *dk = NULL;
+        if (DP) {
+            dc = (float *)malloc((size_t)nn * 12); dk = (uint8_t *)calloc(nn, 1);
+            for (uint32_t q = n_order; q-- > 0;) {
+                uint32_t i = order[q], l = left[i], r = right[i];
+                float Cl[3], Cr[3];
+                if (l & 0x80000000u) { float a = half_area3(lmin + 3 * (l & 0x7FFFFFFFu), lmax + 3 * (l & 0x7FFFFFFFu)); Cl[0] = Cl[1] = Cl[2] = a; }
+                else { Cl[0] = dc[3 * l]; Cl[1] = dc[3 * l + 1]; Cl[2] = dc[3 * l + 2]; }
+                if (r & 0x80000000u) { float a = half_area3(lmin + 3 * (r & 0x7FFFFFFFu), lmax + 3 * (r & 0x7FFFFFFFu)); Cr[0] = Cr[1] = Cr[2] = a; }
+                else { Cr[0] = dc[3 * r]; Cr[1] = dc[3 * r + 1]; Cr[2] = dc[3 * r + 2]; }
+                float d2 = Cl[0] + Cr[0];
+                float d3 = Cl[0] + Cr[1]; uint32_t k3 = 1; { float b = Cl[1] + Cr[0]; if (b < d3) { d3 = b; k3 = 2; } }
+                float d4 = Cl[0] + Cr[2]; uint32_t k4 = 1; { float b = Cl[1] + Cr[1]; if (b < d4) { d4 = b; k4 = 2; } b = Cl[2] + Cr[0]; if (b < d4) { d4 = b; k4 = 3; } }
+                float A = half_area3(nmin + 3 * i, nmax + 3 * i);
+                float cint = A + d4, cleaf = (float)rcnt[i] * A;
+                uint32_t leaf1 = i != 0 && rcnt[i] <= K && cleaf <= cint;
+                float c1 = leaf1 ? cleaf : cint;
+                uint32_t s2 = d2 < c1; float c2 = s2 ? d2 : c1;
+                uint32_t s3 = d3 < c2; float c3 = s3 ? d3 : c2;
+                dc[3 * i] = c1; dc[3 * i + 1] = c2; dc[3 * i + 2] = c3;
+                dk[i] = (uint8_t)(k4 | ((k3 - 1u) << 2) | (leaf1 << 3) | (s2 << 4) | (s3 << 5));
+            }
+        }
+#define ORC_LIVE(i) ((i) == 0 || (DP ? !(dk[i] & 8u) : rcnt[i] > K))
         /* which binary nodes survive as four-wide nodes.  collapse 0: the nodes at even binary depth (each absorbs its live
          * children).  collapse 1 (default): top-down from the root, a node's two child slots are grown to (up to) four by
          * repeatedly replacing the live internal slot of LARGEST SURFACE AREA by its two children (ties: first slot); the
@@ -975,16 +1063,16 @@ int orc_accel_build(orc_scene *s) {
             uint32_t *queue = (uint32_t *)malloc((size_t)nn * 4), qh = 0, qt = 0;
             queue[qt++] = 0; keepf[0] = 1;
             while (qh < qt) {
-                uint32_t i = queue[qh++], sl[4], m = sah_slots(i, left, right, rcnt, nmin, nmax, K, sl);
+                uint32_t i = queue[qh++], sl[4], m = DP ? dp_slots(i, left, right, dk, sl) : sah_slots(i, left, right, rcnt, nmin, nmax, K, sl);
                 for (uint32_t k = 0; k < m; k++)
-                    if (!(sl[k] & 0x80000000u) && rcnt[sl[k]] > K) { keepf[sl[k]] = 1; wlevel[sl[k]] = wlevel[i] + 1; queue[qt++] = sl[k]; }
+                    if (!(sl[k] & 0x80000000u) && ORC_LIVE(sl[k])) { keepf[sl[k]] = 1; wlevel[sl[k]] = wlevel[i] + 1; queue[qt++] = sl[k]; }
             }
             free(queue);
         } else {
             for (uint32_t i = 0; i < nn; i++) { keepf[i] = ORC_LIVE(i) && (!W4 || (depth[i] & 1u) == 0); wlevel[i] = W4 ? depth[i] / 2u : depth[i]; }
         }
 #define ORC_KEEP(i) (keepf[i])
-#define ORC_SLOTS(i, sl, m) do { if (W4 && s->collapse) m = sah_slots(i, left, right, rcnt, nmin, nmax, K, sl); else { \
+#define ORC_SLOTS(i, sl, m) do { if (DP) m = dp_slots(i, left, right, dk, sl); else if (W4 && s->collapse) m = sah_slots(i, left, right, rcnt, nmin, nmax, K, sl); else { \
             uint32_t c2_[2] = {left[i], right[i]}; m = 0; \
             for (int c_ = 0; c_ < 2; c_++) { uint32_t ch_ = c2_[c_]; \
                 if (W4 && !(ch_ & 0x80000000u) && ORC_LIVE(ch_)) { sl[m++] = left[ch_]; sl[m++] = right[ch_]; } else sl[m++] = ch_; } } } while (0)
@@ -1061,7 +1149,7 @@ int orc_accel_build(orc_scene *s) {
 #undef ORC_LIVE
 #undef ORC_KEEP
 #undef ORC_SLOTS
-        free(keepf); free(wlevel);
+        free(keepf); free(wlevel); free(order); free(dc); free(dk);
         free(left); free(right); free(rlo); free(rcnt); free(nmin); free(nmax); free(stack); free(state); free(depth); free(newidx);
     }
     free(bmin); free(bmax); free(cp); free(lmin); free(lmax);
@@ -1146,6 +1234,8 @@ static inline int slab(const float *bx, const float o[3], const float inv[3], fl
     return tn <= tf;
 }
 #define ORC_STACK 256
+static uint32_t *g_visit_hist; /* debug: per-node visit counters (tests/experiments/tree_quality.py) */
+void orc_debug_set_visit_hist(uint32_t *h) { g_visit_hist = h; }
 #define ORC_EMPTY 0xFFFFFFFFu
 /* Closest / any hit.  Children are visited nearest first (four-wide any-hit: FARTHEST first; ties as the sorting network leaves them), the
  * others are pushed so that they pop in that order; no re-cull on pop.  A leaf reference holds 1..8 triangles, tested in order. */
@@ -1192,6 +1282,7 @@ static void traverse(const orc_scene *s, const float o[3], const float d[3], flo
                 continue;
             }
             nn++;
+            if (g_visit_hist) __atomic_fetch_add(&g_visit_hist[cur], 1u, __ATOMIC_RELAXED);
             uint32_t ref[4]; int nh = 0;
             if (W4) {
                 const int QN = (int)s->node_quant;
@@ -1515,7 +1606,7 @@ static int bsdf_sample(const bsdf_t *b, const float wo[3], float u0, float u1, f
 typedef struct {
     const orc_scene *s; const orc_gconst *g; uint32_t x0, y0, x1, y1;
     uint32_t *gbuffer; float *depth; const uint32_t *gb_in; const float *depth_in; const float *prev; float *light;
-    const float *in; float *out; uint64_t (*counts)[4];
+    const float *in; float *out; uint64_t (*counts)[6];
 } pass_job;
 
 /* gbuffer.slang:8-21 */
@@ -1560,7 +1651,7 @@ static void refmode_body(void *c, uint32_t bgn, uint32_t end, int tid) {
     const uint32_t flags = g->pad[0], B = g->bounces, S = g->samples;
     const uint32_t dims = flags ? 8u : 2u;
     const int nee = (flags & ORC_F_NEE_SKY) && s->sky, bnz = (flags & ORC_F_BLUENOISE) && s->bn, spec = (flags & ORC_F_SPECULAR) != 0;
-    uint64_t n_ext = 0, n_sh = 0, n_nodes = 0, n_tris = 0;
+    uint64_t n_ext = 0, n_sh = 0, n_nodes = 0, n_tris = 0, n_sh_nodes = 0, n_sh_tris = 0;
     for (uint32_t i = bgn; i < end; i++) {
         uint32_t px = j->x0 + i % rw, py = j->y0 + i / rw;
         size_t pi = (size_t)py * W + px;
@@ -1634,7 +1725,7 @@ static void refmode_body(void *c, uint32_t bgn, uint32_t end, int tid) {
                         hit_t sh;
                         uint32_t cn, ct;
                         traverse(s, o, wl, 0.001f, ORC_BACKGROUND_DEPTH, 1, &sh, &cn, &ct);
-                        n_sh++; n_nodes += cn; n_tris += ct;
+                        n_sh++; n_nodes += cn; n_tris += ct; n_sh_nodes += cn; n_sh_tris += ct;
                         if (sh.prim == ORC_MISS) for (int k = 0; k < 3; k++) L[k] += (T[k] * fv[k]) * (rad[k] * scale);
                     }
                 }
@@ -1663,19 +1754,19 @@ static void refmode_body(void *c, uint32_t bgn, uint32_t end, int tid) {
             out[3] = 0.0f;
         }
     }
-    if (j->counts) { j->counts[tid][0] = n_ext; j->counts[tid][1] = n_sh; j->counts[tid][2] = n_nodes; j->counts[tid][3] = n_tris; }
+    if (j->counts) { j->counts[tid][0] = n_ext; j->counts[tid][1] = n_sh; j->counts[tid][2] = n_nodes; j->counts[tid][3] = n_tris; j->counts[tid][4] = n_sh_nodes; j->counts[tid][5] = n_sh_tris; }
 }
 void orc_pass_reference_mode(const orc_scene *s, const orc_gconst *g, uint32_t x0, uint32_t y0, uint32_t x1,
                              uint32_t y1, const uint32_t *gbuffer, const float *depth, const float *prev_light,
                              float *light, uint64_t *ray_counts, int n_threads) {
     pass_job j; memset(&j, 0, sizeof(j));
-    uint64_t counts[256][4]; memset(counts, 0, sizeof(counts));
+    uint64_t counts[256][6]; memset(counts, 0, sizeof(counts));
     j.s = s; j.g = g; j.x0 = x0; j.y0 = y0; j.x1 = x1; j.y1 = y1; j.gb_in = gbuffer; j.depth_in = depth;
     j.prev = prev_light; j.light = light; j.counts = counts;
     parallel_for((x1 - x0) * (y1 - y0), n_threads, refmode_body, &j);
     if (ray_counts) {
-        for (int k = 0; k < 4; k++) ray_counts[k] = 0;
-        for (int t = 0; t < 256; t++) for (int k = 0; k < 4; k++) ray_counts[k] += counts[t][k];
+        for (int k = 0; k < 6; k++) ray_counts[k] = 0;
+        for (int t = 0; t < 256; t++) for (int k = 0; k < 6; k++) ray_counts[k] += counts[t][k];
     }
 }
 /* postprocess.slang:90-112 */

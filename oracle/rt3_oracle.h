@@ -108,8 +108,12 @@ int orc_scene_set_texture(orc_scene *s, uint32_t index, const uint8_t *rgba_srgb
  * quantized (width 4 only): 0 = 128 B fp32 boxes, 1 = 64 B nodes with 8-bit conservative child boxes and explicit
  * references, 2 = compact 48 B nodes (same boxes; references implied by node_base / tri_base + one nibble per child) */
 void orc_accel_set_layout(orc_scene *s, uint32_t leaf_max, uint32_t node_width, uint32_t quantized);
-/* four-wide collapse rule: 1 = surface-area greedy (default), 0 = even binary depth */
+/* four-wide collapse rule: 0 = even binary depth, 1 = surface-area greedy, 2 = cost-driven (bottom-up SAH dynamic programme that
+ * also decides which subtrees become multi-triangle leaves; implies tree order) */
 void orc_accel_set_collapse(orc_scene *s, uint32_t mode);
+/* tree order: triangle records re-ordered depth-first along the final binary tree, so that every subtree is a contiguous range
+ * (lets the SAH top go down to single triangles, cluster_size 1, with multi-triangle leaves formed above them) */
+void orc_accel_set_tree_order(orc_scene *s, uint32_t on);
 /* SAH top: the tree above Karras subtrees of at most cluster_size triangles is re-linked by binned SAH (0 = plain LBVH; default 2) */
 void orc_accel_set_sah_top(orc_scene *s, uint32_t cluster_size);
 uint32_t orc_accel_node_words(const orc_scene *s);
@@ -146,7 +150,7 @@ void orc_hit_info(const orc_scene *s, uint32_t prim, float bu, float bv, float s
 void orc_pass_gbuffer(const orc_scene *s, const orc_gconst *g, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
                       uint32_t *gbuffer /*W*H*4*/, float *depth /*W*H*/, int n_threads);
 /* refrence_mode.slang:14-66 ; light/prev_light RGBA32F. ray_counts[0]=extension rays, [1]=shadow rays,
- * [2]=BVH nodes visited, [3]=triangles tested (all summed, may be NULL) */
+ * [2]=BVH nodes visited, [3]=triangles tested (all rays), [4], [5] = the shadow rays' share of [2], [3] (6 words, may be NULL) */
 void orc_pass_reference_mode(const orc_scene *s, const orc_gconst *g, uint32_t x0, uint32_t y0, uint32_t x1,
                              uint32_t y1, const uint32_t *gbuffer, const float *depth, const float *prev_light,
                              float *light, uint64_t *ray_counts, int n_threads);

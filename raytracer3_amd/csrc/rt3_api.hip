@@ -1036,6 +1036,7 @@ int rt3_accel_build(rt3_ctx* c, uint32_t* out_handle) {
     // the vertex / index buffers may have been replaced since rt3_scene_set_geometry checked its ranges against them
     if (int r = validate_geometry(c, c->h_geoms.data(), c->h_prim_counts.data(), (uint32_t)c->h_geoms.size())) return r;
     HIPC(c, hipStreamSynchronize(c->stream));
+    c->accel_built = false;  // until the rebuild has succeeded: a failed one must leave RT3_E_STATE behind, not an empty tree
     dev_free(c->bvh.nodes);
     dev_free(c->bvh.tris);
     dev_free(c->bvh.tri_shade);
@@ -1201,6 +1202,17 @@ int rt3_image_unpack_tiles(rt3_ctx* c, uint32_t image, uint32_t rank, uint32_t n
     } while (0)
 static_assert(sizeof(ncclUniqueId) == RT3_COMM_ID_BYTES, "RT3_COMM_ID_BYTES must be sizeof(ncclUniqueId)");
 
+// A failed send / receive leaves a half-posted exchange behind: peers would block on operations that are never matched and the next
+// gather on this communicator would hang with them.  Abort it (ncclCommAbort also ends an open group) and drop it, so that the next
+// call answers RT3_E_STATE instead; the host then decides (bench.py: the run fails, nothing is reported as measured).
+static int comm_abort(rt3_ctx* c, const std::string& what) {
+    if (c->comm) {
+        (void)ncclCommAbort(c->comm);
+        c->comm = nullptr;
+        c->comm_size = 0;
+    }
+    return fail(c, RT3_E_COMM, what + " (communicator aborted)");
+}
 static int get_gather_layout(rt3_ctx* c, uint32_t w, uint32_t h, uint32_t root, uint32_t n_ranks, GatherLayout** out) {
     for (auto& g : c->gather_layouts)
         if (g.w == w && g.h == h && g.root == root && g.n_ranks == n_ranks) {
@@ -1220,7 +1232,13 @@ static int get_gather_layout(rt3_ctx* c, uint32_t w, uint32_t h, uint32_t root, 
     }
     gl.off[n_ranks] = all.size();
     HIPC(c, hipMalloc((void**)&gl.dev, (all.size() ? all.size() : 1) * 4));
-    if (!all.empty()) HIPC(c, hipMemcpy(gl.dev, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+    if (!all.empty()) {
+        hipError_t e = hipMemcpy(gl.dev, all.data(), all.size() * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(gl.dev);  // not yet owned by the context's layout cache
+            return fail(c, RT3_E_HIP, std::string("gather layout upload: ") + hipGetErrorString(e));
+        }
+    }
     c->gather_layouts.push_back(gl);
     *out = &c->gather_layouts.back();
     return RT3_OK;
@@ -1311,7 +1329,8 @@ int rt3_gather_tiles(rt3_ctx* c, uint32_t image, uint32_t root) {
         }
         HIPC(c, hipGetLastError());
         ScopedTimer t(c, CAT_GATHER);
-        NCCLC(c, ncclSend(c->gather_buf, (size_t)pl->count * 4, ncclFloat, (int)root, c->comm, c->stream));
+        ncclResult_t se = ncclSend(c->gather_buf, (size_t)pl->count * 4, ncclFloat, (int)root, c->comm, c->stream);
+        if (se != ncclSuccess) return comm_abort(c, std::string("ncclSend: ") + ncclGetErrorString(se));
         return RT3_OK;
     }
     GatherLayout* gl;
@@ -1328,12 +1347,10 @@ int rt3_gather_tiles(rt3_ctx* c, uint32_t image, uint32_t root) {
             const uint64_t cnt = gl->off[p + 1] - gl->off[p];
             if (p == root || cnt == 0) continue;
             ncclResult_t e = ncclRecv((char*)c->gather_buf + gl->off[p] * 16, (size_t)cnt * 4, ncclFloat, (int)p, c->comm, c->stream);
-            if (e != ncclSuccess) {
-                (void)ncclGroupEnd();
-                return fail(c, RT3_E_COMM, std::string("ncclRecv: ") + ncclGetErrorString(e));
-            }
+            if (e != ncclSuccess) return comm_abort(c, std::string("ncclRecv: ") + ncclGetErrorString(e));
         }
-        NCCLC(c, ncclGroupEnd());
+        ncclResult_t ge = ncclGroupEnd();
+        if (ge != ncclSuccess) return comm_abort(c, std::string("ncclGroupEnd: ") + ncclGetErrorString(ge));
     }
     ScopedTimer t(c, CAT_OTHER);
     launch_unpack_tiles(c->stream, gl->dev, (uint32_t)total, r->w, c->gather_buf, r->ptr);  // stream-ordered behind the receives

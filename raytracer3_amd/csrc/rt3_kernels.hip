@@ -93,10 +93,11 @@ void set_pool_chunk(uint32_t v) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pool_chun
 static unsigned g_trace_max_blocks = kExtendMaxBlocks;  // persistent traversal workgroups per launch (RT3_OPT_TRACE_BLOCKS)
 void set_trace_blocks(uint32_t v) { g_trace_max_blocks = v; }
 
-constexpr uint32_t kTopNodes = 128;  // 8 KiB
+constexpr uint32_t kTopNodes = kTopCacheNodes;  // 8 KiB; ONE constant (rt3_internal.hpp) sizes the builder's array and the LDS copies
 // copies the builder's top-of-tree array into LDS (kernel-uniform: either every thread of every block does, or none)
 __device__ __forceinline__ bool load_top(float4* s_top, const float4* __restrict__ top, uint32_t n_top) {
     if (top == nullptr || n_top == 0u) return false;
+    n_top = n_top < kTopNodes ? n_top : kTopNodes;  // never past the LDS array, whatever the host read back
     for (uint32_t i = threadIdx.x; i < 4u * n_top; i += kExtendBlock) s_top[i] = top[i];
     __syncthreads();
     return true;

@@ -56,18 +56,28 @@ int main(int argc, char** argv) {
             const char* uid_file = getenv("RT3_UID_FILE");
             if (!uid_file) throw std::runtime_error("RT3_UID_FILE is not set");
             unsigned char id[RT3_COMM_ID_BYTES];
+            // The file starts with a nonce the launcher gives every rank of ONE run (RT3_UID_NONCE): a file left behind by an earlier run
+            // carries another nonce and is ignored, instead of handing the ranks a dead ncclUniqueId to hang on.
+            const char* nonce_s = getenv("RT3_UID_NONCE");
+            const unsigned long long nonce = nonce_s ? strtoull(nonce_s, nullptr, 10) : 0ull;
             if (rank == 0) {
                 if (rt3_comm_unique_id(id)) throw std::runtime_error(std::string("rt3_comm_unique_id: ") + rt3_last_error(nullptr));
                 const std::string tmp = std::string(uid_file) + ".tmp";
                 FILE* u = fopen(tmp.c_str(), "wb");
-                if (!u || fwrite(id, 1, sizeof(id), u) != sizeof(id)) throw std::runtime_error("cannot write the id file");
+                if (!u || fwrite(&nonce, 1, sizeof(nonce), u) != sizeof(nonce) || fwrite(id, 1, sizeof(id), u) != sizeof(id)) throw std::runtime_error("cannot write the id file");
                 fclose(u);
                 if (rename(tmp.c_str(), uid_file)) throw std::runtime_error("cannot publish the id file");
             } else {
-                FILE* u = nullptr;
-                for (int tries = 0; tries < 1200 && !(u = fopen(uid_file, "rb")); tries++) std::this_thread::sleep_for(std::chrono::milliseconds(50));
-                if (!u || fread(id, 1, sizeof(id), u) != sizeof(id)) throw std::runtime_error("cannot read the id file");
-                fclose(u);
+                bool got = false;
+                for (int tries = 0; tries < 1200 && !got; tries++) {
+                    unsigned long long seen = ~nonce;
+                    if (FILE* u = fopen(uid_file, "rb")) {
+                        got = fread(&seen, 1, sizeof(seen), u) == sizeof(seen) && seen == nonce && fread(id, 1, sizeof(id), u) == sizeof(id);
+                        fclose(u);
+                    }
+                    if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(50));
+                }
+                if (!got) throw std::runtime_error("no id file with this run's nonce appeared within 60 s");
             }
             ctx.check(rt3_comm_init(ctx.raw(), id, rank, n_ranks), "comm init");  // collective: ncclCommInitRank on this context's device
         }

@@ -47,6 +47,7 @@ def lib():
         L.orc_accel_set_layout.argtypes = [vp, u32, u32, u32]
         L.orc_accel_set_collapse.argtypes = [vp, u32]
         L.orc_accel_set_sah_top.argtypes = [vp, u32]
+        L.orc_accel_set_tree_order.argtypes = [vp, u32]
         L.orc_accel_node_words.restype = u32; L.orc_accel_node_words.argtypes = [vp]
         L.orc_scene_set_vertices.argtypes = [vp, vp, u32]
         L.orc_scene_set_indices.argtypes = [vp, vp, u32]
@@ -94,12 +95,13 @@ def camera_gconst(position, direction, fov_deg, width, height, z_near=0.1, z_far
 
 
 class Scene:
-    def __init__(self, mesh, sky=None, bluenoise=None, build=True, leaf_size=2, node_width=4, quantized=1, collapse=1, sah_top=2):
+    def __init__(self, mesh, sky=None, bluenoise=None, build=True, leaf_size=2, node_width=4, quantized=1, collapse=1, sah_top=2, tree_order=0):
         L = lib()
         self.h = L.orc_scene_create()
         L.orc_accel_set_layout(self.h, leaf_size, node_width, quantized)
         L.orc_accel_set_collapse(self.h, collapse)
         L.orc_accel_set_sah_top(self.h, sah_top)
+        L.orc_accel_set_tree_order(self.h, tree_order)
         self.mesh = mesh
         v = np.ascontiguousarray(mesh.vertices, np.float32); i = np.ascontiguousarray(mesh.indices, np.uint32)
         L.orc_scene_set_vertices(self.h, ptr(v), len(v))
@@ -189,7 +191,7 @@ class Scene:
         x0, y0, x1, y1 = rect or (0, 0, W, H)
         light = np.zeros((H, W, 4), np.float32) if prev is None else prev.copy()
         prev = np.zeros((H, W, 4), np.float32) if prev is None else np.ascontiguousarray(prev, np.float32)
-        counts = np.zeros(4, np.uint64)
+        counts = np.zeros(6, np.uint64)
         lib().orc_pass_reference_mode(self.h, C.byref(g), x0, y0, x1, y1, ptr(gb), ptr(depth), ptr(prev), ptr(light), ptr(counts), threads)
         return light, counts
 

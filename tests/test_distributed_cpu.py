@@ -77,6 +77,13 @@ def test_gather_offsets_skip_the_root():
     assert gather_offsets([4], 0) == [0, 0]
 
 
+def _z(x, y):
+    k = 0
+    for b in range(16):
+        k |= ((x >> b) & 1) << (2 * b) | ((y >> b) & 1) << (2 * b + 1)
+    return k
+
+
 def test_tile_partition_properties():
     import orc
 
@@ -88,8 +95,13 @@ def test_tile_partition_properties():
                 xy = orc.tile_pixels(W, H, r, n)
                 seen[xy[:, 1], xy[:, 0]] += 1
                 sizes.append(len(xy))
-                tiles = {(int(x) // 64, int(y) // 64) for x, y in xy[:: max(1, len(xy) // 200)]}
-                assert all(True for _ in tiles)
+                # tile i (Z-order over the tile grid) belongs to rank i mod n: every pixel this rank lists lies in one of ITS tiles
+                tx, ty = xy[:, 0].astype(np.uint32) // 64, xy[:, 1].astype(np.uint32) // 64
+                tiles_x, tiles_y = (W + 63) // 64, (H + 63) // 64
+                zkeys = sorted((_z(x, y), x, y) for y in range(tiles_y) for x in range(tiles_x))
+                order = {(x, y): i for i, (_, x, y) in enumerate(zkeys)}
+                own = np.array([order[(int(a), int(b))] % n for a, b in zip(tx[:: max(1, len(xy) // 500)], ty[:: max(1, len(xy) // 500)])])
+                assert (own == r).all()
             assert (seen == 1).all()  # every pixel owned exactly once
             if W * H >= 64 * 64 * n * 4:
                 assert max(sizes) - min(sizes) <= 2 * 64 * 64  # interleaving balances the load

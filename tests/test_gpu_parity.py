@@ -614,9 +614,12 @@ def test_cpp_host_renders_the_same_frame(small, tmp_path):
     # the same host as one rank of a multi-GPU frame (RT3_RANKS): tile partition, RCCL communicator from an id carried over a file,
     # rt3_gather_tiles at frame end -- with one rank (all a one-GPU box allows) the gathered frame is the same frame
     out1 = tmp_path / "out_rank.bin"
-    env = dict(os.environ, RT3_RANKS="1", RT3_RANK="0", RT3_UID_FILE=str(tmp_path / "uid.bin"))
+    # a file left behind by an earlier run (other nonce) must be replaced, never handed out: rank 0 publishes {this run's nonce, id}
+    (tmp_path / "uid.bin").write_bytes(b"\x01" * (8 + L.COMM_ID_BYTES))
+    env = dict(os.environ, RT3_RANKS="1", RT3_RANK="0", RT3_UID_FILE=str(tmp_path / "uid.bin"), RT3_UID_NONCE="4242")
     subprocess.check_call([str(exe), str(scene), str(W), str(H), str(spp), str(bounces), str(SPEC), str(frame), str(out1)], env=env)
-    assert (tmp_path / "uid.bin").stat().st_size == L.COMM_ID_BYTES
+    blob = (tmp_path / "uid.bin").read_bytes()
+    assert len(blob) == 8 + L.COMM_ID_BYTES and int.from_bytes(blob[:8], "little") == 4242
     assert np.array_equal(np.fromfile(out1, "<f4").view(np.uint32), data.ravel().view(np.uint32))
 
 
