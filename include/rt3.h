@@ -88,6 +88,15 @@ typedef struct rt3_geometry_info {
     uint32_t _pad[3];
 } rt3_geometry_info;
 
+/* One placed mesh of the world: `Instance{model}` + `Transform{Mat4}` of an entity (src/renderer/world/mod.rs:46-60), the rows
+ * `InstanceInfo{mesh_index, transform}` of the global instance / transform buffers (world/mod.rs:34-38,104-125).  A mesh here is
+ * a run of geometries [geometry_first, geometry_first + geometry_count) of rt3_scene_set_geometry; `transform` is column-major
+ * like glam's Mat4 (object -> world), last row (0, 0, 0, 1) -- the 3 x 4 a VkAccelerationStructureInstanceKHR can hold. */
+typedef struct rt3_instance {
+    uint32_t geometry_first, geometry_count;
+    float transform[16];
+} rt3_instance;
+
 /* frame statistics (no reference equivalent: the reference has no counters) */
 typedef struct rt3_stats {
     uint64_t extension_rays; /* closest-hit rays traced since rt3_stats_reset (primary + bounce) */
@@ -110,6 +119,9 @@ typedef struct rt3_stats {
     uint64_t trace_nodes[2];
     uint64_t trace_tris[2];
     double gather_ms; /* RCCL send / grouped receives of rt3_gather_tiles (the pack / untile kernels are in other_ms) */
+    double accel_build_ms;       /* host wall clock of the last rt3_accel_build, stream synchronised on both sides */
+    uint64_t accel_bulk_copies;  /* host <-> device copies of array size (> 64 KiB) made by rt3_accel_build calls since rt3_stats_reset:
+                                    0 on the default path (the build stays on the GPU; a few KiB of per-geometry tables go up) */
 } rt3_stats;
 
 typedef struct rt3_ctx rt3_ctx;
@@ -149,6 +161,18 @@ int rt3_scene_set_bluenoise(rt3_ctx *ctx, const uint8_t *rgba, uint32_t width, u
 /* base-colour texture `index` (dense indices 0..n-1): RGBA8 with sRGB-encoded colour, sampled bilinearly with repeat
  * addressing at mip 0 like Textures[i].SampleLevel(uvs, 0.0) (hit_logic.slang:31-33; bindless set 2, bindless/mod.rs:38-77) */
 int rt3_scene_set_texture(rt3_ctx *ctx, uint32_t index, const uint8_t *rgba_srgb, uint32_t width, uint32_t height);
+
+/* ---- instances: the reference's world is a list of placed meshes (add_instance / loaded_assets, world/mod.rs:50-101) under a
+ *      top-level acceleration structure (create_acceleration_structure(.., level, ..), vulkan/raytracing.rs:88-148), and hit_info
+ *      turns the shading normal by the instance matrix (hit_logic.slang:23).  Here: n = 0 (the default) places every geometry once
+ *      under the identity.  Otherwise instance i places geometries [first, first + count) under its matrix; the same geometry may be
+ *      placed many times.  There is no separate top level: rt3_accel_build FLATTENS the instances into world-space triangles
+ *      (p' = ((x_axis x + y_axis y) + z_axis z) + w_axis in fp32, glam's transform_point3; identity matrices leave positions
+ *      untouched) and builds one tree over them -- the build takes ~3 ms for 260 k triangles and stays on the GPU, so re-building
+ *      after an instance moved IS the TLAS update (rt3_stats.accel_build_ms).  Primitive ids reported by hits (gbuffer, rt3_trace_rays)
+ *      count through the placed geometries in instance order.  Normals: normalize(M3 * normalize(interpolated)), M3 = upper 3 x 3,
+ *      as hit_logic.slang:22-23 writes it (no inverse transpose).  Call before rt3_accel_build; borrowed for the call. ---- */
+int rt3_scene_set_instances(rt3_ctx *ctx, const rt3_instance *instances, uint32_t n);
 
 /* ---- acceleration structure: create_acceleration_structure (vulkan/raytracing.rs:88-148) -> GPU LBVH.
  *      Returns the handle (tag 3) in *out_handle, like the TLAS registered at bindless/mod.rs:314-337 ---- */
@@ -232,7 +256,8 @@ int rt3_trace_rays(rt3_ctx *ctx, const float *rays, uint32_t n, int any_hit, flo
  *      9 sincos_2pi (u -> sin,cos) 10 atan2 (y,x) 11 rng_seed(px,py,frame)
  *      12 division-free integer helpers (n,d -> n/d, n%d, wrap(int(n), (d & 0xFFFF)+1))
  *      13 octa_decode (fx,fy -> n) 14 sh3Evaluate (dir -> 9 coefficients) 15 64-lane bitonic sort (64 keys -> 64 keys, 64 lane ids)
- *      16 64-lane sum (64 floats -> 1).  in/out: host arrays of 32-bit words. ---- */
+ *      16 64-lane sum (64 floats -> 1) 17 octa_encode16 (n -> the 2 x 16-bit word of a shading-record normal) 18 octa_decode16 (word -> n).
+ *      in/out: host arrays of 32-bit words. ---- */
 int rt3_selftest_eval(rt3_ctx *ctx, int op, const void *in, uint32_t n, void *out);
 
 int rt3_stats_reset(rt3_ctx *ctx);

@@ -402,6 +402,10 @@ struct orc_scene {
     uint32_t *indices; uint32_t n_indices;
     orc_geometry_info *geoms; uint32_t *prim_counts, *first_prim; uint32_t n_geoms;
     uint32_t n_prims; uint32_t *prim_geom;
+    /* [round 3] instances (world/mod.rs:34-60): the world is flattened into (instance, geometry) pairs, instance-major; prim_geom /
+     * first_prim / n_prims describe the FLATTENED primitives, flat_geom / flat_inst name a pair's geometry and instance */
+    orc_instance *inst; uint32_t n_inst;
+    uint32_t n_flat; uint32_t *flat_geom, *flat_inst; uint8_t *flat_identity;
     /* accel */
     uint32_t n_tris, n_nodes, max_depth, leaf_max, node_width, node_quant, collapse, sah_top, tree_order;
     float *nodes;   /* 16 words per node */
@@ -533,6 +537,7 @@ void orc_scene_destroy(orc_scene *s) {
     if (!s) return;
     accel_free(s);
     free(s->verts); free(s->indices); free(s->geoms); free(s->prim_counts); free(s->first_prim); free(s->prim_geom);
+    free(s->inst); free(s->flat_geom); free(s->flat_inst); free(s->flat_identity);
     free(s->sky); free(s->sky_alias); free(s->sky_q); free(s->cdf_marg); free(s->pdf_uv); free(s->bn);
     for (uint32_t i = 0; i < s->n_tex; i++) free(s->tex[i]);
     free(s->tex); free(s->tex_w); free(s->tex_h);
@@ -552,19 +557,56 @@ int orc_scene_set_indices(orc_scene *s, const uint32_t *idx, uint32_t n) {
     s->n_indices = n;
     return 0;
 }
+/* One (instance, geometry) pair per flattened geometry, instance-major; no instances = one identity instance of everything.
+ * The product's flatten_world (rt3_api.hip) makes the same tables. */
+static const float k_identity16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+static int flatten_world(orc_scene *s) {
+    free(s->first_prim); free(s->prim_geom); free(s->flat_geom); free(s->flat_inst); free(s->flat_identity);
+    s->first_prim = s->prim_geom = s->flat_geom = s->flat_inst = NULL; s->flat_identity = NULL;
+    orc_instance whole; whole.geometry_first = 0; whole.geometry_count = s->n_geoms; memcpy(whole.transform, k_identity16, 64);
+    const orc_instance *inst = s->n_inst ? s->inst : &whole;
+    uint32_t ni = s->n_inst ? s->n_inst : 1u, nf = 0;
+    for (uint32_t i = 0; i < ni; i++) {
+        if ((uint64_t)inst[i].geometry_first + inst[i].geometry_count > s->n_geoms) return -1;
+        nf += inst[i].geometry_count;
+    }
+    s->flat_geom = (uint32_t *)malloc((size_t)nf * 4 + 4); s->flat_inst = (uint32_t *)malloc((size_t)nf * 4 + 4);
+    s->flat_identity = (uint8_t *)malloc((size_t)nf + 4); s->first_prim = (uint32_t *)malloc((size_t)nf * 4 + 4);
+    uint32_t total = 0, j = 0;
+    for (uint32_t i = 0; i < ni; i++)
+        for (uint32_t k = 0; k < inst[i].geometry_count; k++, j++) {
+            s->flat_geom[j] = inst[i].geometry_first + k; s->flat_inst[j] = i;
+            s->flat_identity[j] = memcmp(inst[i].transform, k_identity16, 64) == 0;
+            s->first_prim[j] = total; total += s->prim_counts[s->flat_geom[j]];
+        }
+    s->n_flat = nf; s->n_prims = total;
+    s->prim_geom = (uint32_t *)malloc((size_t)total * 4 + 4);
+    for (j = 0; j < nf; j++)
+        for (uint32_t k = 0; k < s->prim_counts[s->flat_geom[j]]; k++) s->prim_geom[s->first_prim[j] + k] = j;
+    return 0;
+}
 int orc_scene_set_geometry(orc_scene *s, const orc_geometry_info *g, const uint32_t *prim_counts, uint32_t n) {
-    free(s->geoms); free(s->prim_counts); free(s->first_prim); free(s->prim_geom);
+    free(s->geoms); free(s->prim_counts);
     s->geoms = (orc_geometry_info *)malloc((size_t)n * sizeof(*g) + 4);
     memcpy(s->geoms, g, (size_t)n * sizeof(*g));
     s->prim_counts = (uint32_t *)malloc((size_t)n * 4 + 4);
-    s->first_prim = (uint32_t *)malloc((size_t)n * 4 + 4);
-    uint32_t total = 0;
-    for (uint32_t i = 0; i < n; i++) { s->prim_counts[i] = prim_counts[i]; s->first_prim[i] = total; total += prim_counts[i]; }
-    s->n_geoms = n; s->n_prims = total;
-    s->prim_geom = (uint32_t *)malloc((size_t)total * 4 + 4);
-    for (uint32_t i = 0; i < n; i++)
-        for (uint32_t k = 0; k < prim_counts[i]; k++) s->prim_geom[s->first_prim[i] + k] = i;
+    for (uint32_t i = 0; i < n; i++) s->prim_counts[i] = prim_counts[i];
+    s->n_geoms = n;
+    if (s->n_inst && flatten_world(s)) { s->n_inst = 0; } /* instances that no longer fit the geometries are dropped */
+    return flatten_world(s);
+}
+/* Instance{model} + Transform{Mat4} (world/mod.rs:46-60): instance i places geometries [first, first + count) under its column-major
+ * matrix; n = 0 restores the default (everything once, identity).  Takes effect at the next orc_accel_build. */
+int orc_scene_set_instances(orc_scene *s, const orc_instance *inst, uint32_t n) {
+    free(s->inst); s->inst = NULL; s->n_inst = 0;
+    if (n) { s->inst = (orc_instance *)malloc((size_t)n * sizeof(*inst)); memcpy(s->inst, inst, (size_t)n * sizeof(*inst)); s->n_inst = n; }
+    if (flatten_world(s)) { free(s->inst); s->inst = NULL; s->n_inst = 0; flatten_world(s); return -1; }
     return 0;
+}
+/* glam Mat4::transform_point3: ((x_axis * x + y_axis * y) + z_axis * z) + w_axis */
+static void transform_point(const float *m, float p[3]) {
+    float x = p[0], y = p[1], z = p[2];
+    for (int r = 0; r < 3; r++) p[r] = m[12 + r] + (m[8 + r] * z + (m[4 + r] * y + m[r] * x));
 }
 int orc_scene_set_bluenoise(orc_scene *s, const uint8_t *rgba, uint32_t w, uint32_t h) {
     free(s->bn);
@@ -698,13 +740,17 @@ static uint64_t expand21(uint32_t v) {
     return x;
 }
 static void tri_positions(const orc_scene *s, uint32_t prim, float a[3], float b[3], float c[3]) {
-    uint32_t g = s->prim_geom[prim], local = prim - s->first_prim[g];
-    const orc_geometry_info *gi = &s->geoms[g];
+    uint32_t fg = s->prim_geom[prim], local = prim - s->first_prim[fg];
+    const orc_geometry_info *gi = &s->geoms[s->flat_geom[fg]];
     uint32_t io = gi->index_offset + 3u * local;
     const float *v0 = s->verts + 8 * (size_t)(gi->vertex_offset + s->indices[io]);
     const float *v1 = s->verts + 8 * (size_t)(gi->vertex_offset + s->indices[io + 1]);
     const float *v2 = s->verts + 8 * (size_t)(gi->vertex_offset + s->indices[io + 2]);
     for (int k = 0; k < 3; k++) { a[k] = v0[k]; b[k] = v1[k]; c[k] = v2[k]; }
+    if (!s->flat_identity[fg]) { /* world space: the instance's matrix (identity instances keep the uploaded bits) */
+        const float *m = s->inst[s->flat_inst[fg]].transform;
+        transform_point(m, a); transform_point(m, b); transform_point(m, c);
+    }
 }
 typedef struct { uint64_t code; uint32_t prim; } code_prim;
 static int cmp_code_prim(const void *pa, const void *pb) {
@@ -1417,18 +1463,43 @@ void orc_trace_brute(const orc_scene *s, const float *rays, uint32_t n, float *t
 /* ------------------------------------------------------------------------------------------------ hit_info */
 /* hit_logic.slang:5-40 with GeometryInfo.transform := identity, Vertex.color := 1;
  * surf = albedo[3] emissive[3] normal[3] roughness metalness */
+/* [round 3] The vertex normals of the shading records are kept in the reference's octahedral map (packing.slang:64-86), 16 bits per
+ * coordinate: a vertex normal IS octa_decode16(octa_encode16(n)) -- the scene representation on both sides of the ABI (the product's
+ * 16-byte shading record {n0, n1, n2, geometry}).  A zero (or non-finite) normal encodes +z. */
+void orc_octa_decode(float fx, float fy, float n[3]);
+uint32_t orc_octa_encode16(const float nin[3]) {
+    const float s = fabsf(nin[0]) + fabsf(nin[1]) + fabsf(nin[2]);
+    if (!(s > 0.0f) || !(s <= 3.4028234663852886e38f)) return 0x80008000u;
+    float x = nin[0] / s, y = nin[1] / s;
+    const float z = nin[2] / s;
+    if (z < 0.0f) { /* octa_wrap, :64-66 */
+        const float wx = (1.0f - fabsf(y)) * ((x >= 0.0f ? 1.0f : 0.0f) * 2.0f - 1.0f);
+        const float wy = (1.0f - fabsf(x)) * ((y >= 0.0f ? 1.0f : 0.0f) * 2.0f - 1.0f);
+        x = wx; y = wy;
+    }
+    x = x * 0.5f + 0.5f; y = y * 0.5f + 0.5f;
+    const uint32_t qx = (uint32_t)(fminx(fmaxx(x, 0.0f), 1.0f) * 65535.0f + 0.5f), qy = (uint32_t)(fminx(fmaxx(y, 0.0f), 1.0f) * 65535.0f + 0.5f);
+    return qx | (qy << 16);
+}
+void orc_octa_decode16(uint32_t w, float n[3]) { orc_octa_decode((float)(w & 0xFFFFu) * (1.0f / 65535.0f), (float)(w >> 16) * (1.0f / 65535.0f), n); }
 void orc_hit_info(const orc_scene *s, uint32_t prim, float bu, float bv, float surf[11]) {
-    uint32_t g = s->prim_geom[prim], local = prim - s->first_prim[g];
-    const orc_geometry_info *gi = &s->geoms[g];
+    uint32_t fg = s->prim_geom[prim], local = prim - s->first_prim[fg];
+    const orc_geometry_info *gi = &s->geoms[s->flat_geom[fg]];
     uint32_t io = gi->index_offset + 3u * local;
     const float *v0 = s->verts + 8 * (size_t)(gi->vertex_offset + s->indices[io]);
     const float *v1 = s->verts + 8 * (size_t)(gi->vertex_offset + s->indices[io + 1]);
     const float *v2 = s->verts + 8 * (size_t)(gi->vertex_offset + s->indices[io + 2]);
     float b0 = 1.0f - bu - bv, b1 = bu, b2 = bv;
-    float n[3];
-    for (int k = 0; k < 3; k++) n[k] = v0[3 + k] * b0 + v1[3 + k] * b1 + v2[3 + k] * b2;
-    normalize3(n); /* :24 */
-    normalize3(n); /* :25 (identity transform, second normalize kept) */
+    float n[3], n0[3], n1[3], n2[3];
+    orc_octa_decode16(orc_octa_encode16(v0 + 3), n0); orc_octa_decode16(orc_octa_encode16(v1 + 3), n1); orc_octa_decode16(orc_octa_encode16(v2 + 3), n2);
+    for (int k = 0; k < 3; k++) n[k] = n0[k] * b0 + n1[k] * b1 + n2[k] * b2;
+    normalize3(n); /* :22 */
+    if (!s->flat_identity[fg]) { /* :23 mul(geometryInfo.transform, float4(normal, 0.0)).xyz */
+        const float *m = s->inst[s->flat_inst[fg]].transform;
+        float x = n[0], y = n[1], z = n[2];
+        for (int r = 0; r < 3; r++) n[r] = m[8 + r] * z + (m[4 + r] * y + m[r] * x);
+    }
+    normalize3(n); /* :23 */
     surf[0] = gi->base_color[0]; surf[1] = gi->base_color[1]; surf[2] = gi->base_color[2];
     if (gi->base_color_texture_index > -1 && (uint32_t)gi->base_color_texture_index < s->n_tex) { /* :27,31-33 */
         float uu = v0[6] * b0 + v1[6] * b1 + v2[6] * b2, vv = v0[7] * b0 + v1[7] * b1 + v2[7] * b2, tc[3];

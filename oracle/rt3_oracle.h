@@ -93,6 +93,12 @@ void orc_camera_gconst(const float pos[3], const float dir[3], float fov_y, floa
                        float width, float height, orc_gconst *out);
 void orc_primary_ray(const orc_gconst *g, uint32_t px, uint32_t py, float o[3], float d[3]); /* gbuffer_helpers.slang:85-103 */
 
+/* Instance{model} + Transform{Mat4} of the reference's world (src/renderer/world/mod.rs:34-60); == rt3_instance */
+typedef struct orc_instance {
+    uint32_t geometry_first, geometry_count;
+    float transform[16]; /* column-major, object -> world, last row (0, 0, 0, 1) */
+} orc_instance;
+
 /* ---- scene ---- */
 orc_scene *orc_scene_create(void);
 void orc_scene_destroy(orc_scene *s);
@@ -100,6 +106,7 @@ void orc_scene_destroy(orc_scene *s);
 int orc_scene_set_vertices(orc_scene *s, const float *pnt, uint32_t n_vertices);
 int orc_scene_set_indices(orc_scene *s, const uint32_t *idx, uint32_t n_indices);
 int orc_scene_set_geometry(orc_scene *s, const orc_geometry_info *g, const uint32_t *prim_counts, uint32_t n);
+int orc_scene_set_instances(orc_scene *s, const orc_instance *inst, uint32_t n); /* n = 0: every geometry once, identity */
 int orc_scene_set_sky(orc_scene *s, const float *rgb, uint32_t w, uint32_t h);
 int orc_scene_set_bluenoise(orc_scene *s, const uint8_t *rgba, uint32_t w, uint32_t h);
 int orc_scene_set_texture(orc_scene *s, uint32_t index, const uint8_t *rgba_srgb, uint32_t w, uint32_t h); /* hit_logic.slang:31-33 */
@@ -161,6 +168,8 @@ void orc_pass_postprocess(const orc_scene *s, const orc_gconst *g, uint32_t x0, 
 /* ---- probe-GI passes (rt3_oracle_probes.c).  probes = 8x8-texel cells of the probe atlas, one per
  * 16x16 pixel block; atlas images are (8*probes_x) x (8*probes_y); W, H come from g->window_size. ---- */
 void orc_octa_decode(float fx, float fy, float n[3]);           /* packing.slang:77-86 */
+uint32_t orc_octa_encode16(const float n[3]);                   /* packing.slang:64-75 + 16-bit unorm per coordinate */
+void orc_octa_decode16(uint32_t w, float n[3]);
 void orc_sh3_evaluate(const float d[3], float sh[9]);           /* spherical_harmonics.slang:30-44, sh[r*3+c] */
 void orc_wave_sort64(float keys[64], uint32_t idx[64]);         /* math.slang:140-160 over the 64 lanes of a wave */
 float orc_wave_sum64(const float v[64]);                        /* WaveActiveSum, fixed butterfly order */

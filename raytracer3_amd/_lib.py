@@ -23,6 +23,7 @@ OPT_WIDE_COLLAPSE, OPT_POOL_CHUNK, OPT_FUSED_TRACE, OPT_SAH_TOP, OPT_TRACE_BLOCK
 EXPORTS = [
     "rt3_create", "rt3_destroy", "rt3_last_error", "rt3_device_name", "rt3_set_option",
     "rt3_scene_set_vertices", "rt3_scene_set_indices", "rt3_scene_set_geometry", "rt3_scene_set_sky", "rt3_scene_set_bluenoise", "rt3_scene_set_texture",
+    "rt3_scene_set_instances",
     "rt3_accel_build", "rt3_accel_info", "rt3_accel_download", "rt3_sky_download",
     "rt3_buffer_create", "rt3_image_create", "rt3_image_import", "rt3_resource_upload", "rt3_resource_download", "rt3_resource_device_ptr",
     "rt3_set_tile_partition", "rt3_tile_pixel_count", "rt3_image_pack_tiles", "rt3_image_unpack_tiles",
@@ -45,7 +46,13 @@ class Stats(C.Structure):
                 ("extend_launches", C.c_uint64), ("extend_ms", C.c_double), ("shadow_launches", C.c_uint64), ("shadow_ms", C.c_double),
                 ("shade_ms", C.c_double), ("other_ms", C.c_double),
                 ("trace_launches", C.c_uint64), ("trace_ms", C.c_double), ("trace_rays", C.c_uint64 * 2), ("trace_nodes", C.c_uint64 * 2),
-                ("trace_tris", C.c_uint64 * 2), ("gather_ms", C.c_double)]
+                ("trace_tris", C.c_uint64 * 2), ("gather_ms", C.c_double), ("accel_build_ms", C.c_double), ("accel_bulk_copies", C.c_uint64)]
+
+
+class Instance(C.Structure):
+    """rt3_instance: Instance{model} + Transform{Mat4} (src/renderer/world/mod.rs:34-60); transform column-major like glam's Mat4."""
+
+    _fields_ = [("geometry_first", C.c_uint32), ("geometry_count", C.c_uint32), ("transform", C.c_float * 16)]
 
 
 assert C.sizeof(GConst) == 304
@@ -89,6 +96,7 @@ def load():
         "rt3_scene_set_sky": (i32, [vp, vp, u32, u32]),
         "rt3_scene_set_bluenoise": (i32, [vp, vp, u32, u32]),
         "rt3_scene_set_texture": (i32, [vp, u32, vp, u32, u32]),
+        "rt3_scene_set_instances": (i32, [vp, vp, u32]),
         "rt3_accel_build": (i32, [vp, pu32]),
         "rt3_accel_info": (i32, [vp, pu32, pu32, pu32, pu32]),
         "rt3_accel_download": (i32, [vp, vp, sz, vp, sz]),

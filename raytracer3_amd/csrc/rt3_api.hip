@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <chrono>
 #include <string>
 #include <vector>
 
@@ -69,9 +70,13 @@ struct rt3_ctx {
     uint32_t n_verts = 0;
     uint32_t* d_indices = nullptr;
     uint32_t n_indices = 0;
-    GeometryInfoDev* d_geoms = nullptr;
-    uint32_t n_geoms = 0, n_prims = 0;
+    FlatGeomDev* d_geoms = nullptr;          // one entry per (instance, geometry): built by rt3_accel_build (flatten_world)
+    ShadeGeomDev* d_shade_geoms = nullptr;   // the same table as hit_info reads it
+    uint32_t n_geoms = 0, n_prims = 0;       // uploaded geometries / their primitives (one instance of each)
+    uint32_t n_flat_geoms = 0, n_flat_prims = 0;  // after flattening: what the acceleration structure and the shading records cover
     uint32_t *d_prim_geom = nullptr, *d_first_prim = nullptr;
+    std::vector<rt3_instance> h_instances;   // empty = one identity instance of every geometry
+    uint64_t bulk_copies = 0;                // host <-> device copies of more than 64 KiB made by rt3_accel_build (rt3_stats.accel_bulk_copies)
     uint2* d_sky = nullptr;  // 8-byte texels {RGB9E5, pdf_uv} in 4 x 4 tiles
     float* d_cdf_marg = nullptr;
     uint32_t *d_sky_alias = nullptr, *d_guide_marg = nullptr;
@@ -223,9 +228,12 @@ SceneDev scene_dev(const rt3_ctx* c) {
     s.verts = c->d_verts;
     s.indices = c->d_indices;
     s.geoms = c->d_geoms;
+    s.shade_geoms = c->d_shade_geoms;
+    s.n_geoms = c->n_flat_geoms;
     s.prim_geom = c->d_prim_geom;
     s.first_prim = c->d_first_prim;
     s.tri_shade = c->bvh.tri_shade;
+    s.tri_uv = c->bvh.tri_uv;
     s.guide_marg = c->d_guide_marg;
     s.sky = c->d_sky;
     s.sky_alias = c->d_sky_alias;
@@ -689,10 +697,10 @@ void rt3_destroy(rt3_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    dev_free(c->d_verts); dev_free(c->d_indices); dev_free(c->d_geoms); dev_free(c->d_prim_geom); dev_free(c->d_first_prim);
+    dev_free(c->d_verts); dev_free(c->d_indices); dev_free(c->d_geoms); dev_free(c->d_shade_geoms); dev_free(c->d_prim_geom); dev_free(c->d_first_prim);
     dev_free(c->d_tex_pixels); dev_free(c->d_tex_table); dev_free(c->d_srgb_lut);
     dev_free(c->d_sky); dev_free(c->d_sky_alias); dev_free(c->d_cdf_marg); dev_free(c->d_bn);
-    dev_free(c->bvh.nodes); dev_free(c->bvh.tris); dev_free(c->bvh.tri_shade); dev_free(c->bvh.top); dev_free(c->d_guide_marg);
+    dev_free(c->bvh.nodes); dev_free(c->bvh.tris); dev_free(c->bvh.tri_shade); dev_free(c->bvh.tri_uv); dev_free(c->bvh.top); dev_free(c->d_guide_marg);
     c->build_arena.release();
     for (auto& r : c->resources)
         if (r.owned && r.ptr) (void)hipFree(r.ptr);
@@ -823,26 +831,14 @@ int rt3_scene_set_geometry(rt3_ctx* c, const rt3_geometry_info* g, const uint32_
     if (!c || ((!g || !prim_counts) && n)) return fail(c, RT3_E_INVALID, "geometry NULL");
     HIPC(c, hipSetDevice(c->device));
     if (int r = validate_geometry(c, g, prim_counts, n)) return r;
-    std::vector<uint32_t> first(n ? n : 1), pg;
     uint64_t total = 0;
     int64_t max_tex = -1;
     for (uint32_t i = 0; i < n; i++) {
         if (g[i].base_color_texture_index > max_tex) max_tex = g[i].base_color_texture_index;
-        first[i] = (uint32_t)total;
         total += prim_counts[i];
     }
     if (total > 0x7FFFFFFFull) return fail(c, RT3_E_INVALID, "too many primitives");
-    pg.resize(total ? total : 1);
-    for (uint32_t i = 0; i < n; i++)
-        for (uint32_t k = 0; k < prim_counts[i]; k++) pg[first[i] + k] = i;
-    if (int r = dev_alloc(c, &c->d_geoms, (size_t)n)) return r;
-    if (int r = dev_alloc(c, &c->d_first_prim, (size_t)n)) return r;
-    if (int r = dev_alloc(c, &c->d_prim_geom, (size_t)total)) return r;
-    if (n) {
-        HIPC(c, hipMemcpy(c->d_geoms, g, (size_t)n * 64, hipMemcpyHostToDevice));
-        HIPC(c, hipMemcpy(c->d_first_prim, first.data(), (size_t)n * 4, hipMemcpyHostToDevice));
-    }
-    if (total) HIPC(c, hipMemcpy(c->d_prim_geom, pg.data(), (size_t)total * 4, hipMemcpyHostToDevice));
+    // (the device tables -- one entry per (instance, geometry) -- are made by rt3_accel_build, which knows the instances)
     c->h_geoms.assign(g, g + n);
     c->h_prim_counts.assign(prim_counts, prim_counts + n);
     c->n_geoms = n;
@@ -1027,21 +1023,100 @@ int rt3_sky_download(rt3_ctx* c, uint32_t* alias, uint32_t* texels, float* marg,
     return RT3_OK;
 }
 
+// world/mod.rs:34-60,104-125: InstanceInfo{mesh_index, transform} + Transform{Mat4}, global instance / transform buffers
+int rt3_scene_set_instances(rt3_ctx* c, const rt3_instance* inst, uint32_t n) {
+    if (!c || (!inst && n)) return fail(c, RT3_E_INVALID, "instances NULL");
+    for (uint32_t i = 0; i < n; i++) {
+        for (int k = 0; k < 16; k++)
+            if (!(std::fabs(inst[i].transform[k]) <= 1.0e18f)) return fail(c, RT3_E_INVALID, "instance " + std::to_string(i) + ": transform is not finite (or beyond 1e18)");
+        const float* m = inst[i].transform;
+        if (m[3] != 0.0f || m[7] != 0.0f || m[11] != 0.0f || m[15] != 1.0f)
+            return fail(c, RT3_E_INVALID, "instance " + std::to_string(i) + ": the last row of the transform must be (0, 0, 0, 1) (VkTransformMatrixKHR is 3 x 4 too)");
+    }
+    c->h_instances.assign(inst, inst + n);
+    c->accel_built = false;
+    return RT3_OK;
+}
+// One (instance, geometry) pair per entry, instance-major; no instances = one identity instance of everything.  A few KiB of tables
+// go up; primitive -> entry is filled in on the device (k_prim_geom), so a rebuild after a moved instance copies nothing big.
+static int flatten_world(rt3_ctx* c) {
+    static const float kIdentity[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+    rt3_instance whole;
+    whole.geometry_first = 0;
+    whole.geometry_count = c->n_geoms;
+    memcpy(whole.transform, kIdentity, sizeof(kIdentity));
+    const rt3_instance* inst = c->h_instances.empty() ? &whole : c->h_instances.data();
+    const size_t n_inst = c->h_instances.empty() ? 1 : c->h_instances.size();
+    std::vector<FlatGeomDev> flat;
+    std::vector<ShadeGeomDev> shade;
+    std::vector<uint32_t> first;
+    uint64_t total = 0;
+    for (size_t i = 0; i < n_inst; i++) {
+        if ((uint64_t)inst[i].geometry_first + inst[i].geometry_count > c->n_geoms)
+            return fail(c, RT3_E_INVALID, "instance " + std::to_string(i) + ": geometry range exceeds the geometries set (rt3_scene_set_geometry)");
+        const float* m = inst[i].transform;
+        const bool identity = memcmp(m, kIdentity, sizeof(kIdentity)) == 0;
+        for (uint32_t k = 0; k < inst[i].geometry_count; k++) {
+            const uint32_t g = inst[i].geometry_first + k;
+            FlatGeomDev f;
+            memset(&f, 0, sizeof(f));
+            static_assert(sizeof(rt3_geometry_info) == sizeof(GeometryInfoDev), "geometry info layouts");
+            memcpy(&f.g, &c->h_geoms[g], sizeof(f.g));
+            for (int col = 0; col < 4; col++)
+                for (int row = 0; row < 3; row++) f.m[3 * col + row] = m[4 * col + row];
+            f.identity = identity ? 1u : 0u;
+            f.geom = g;
+            f.instance = (uint32_t)i;
+            ShadeGeomDev sg;
+            memset(&sg, 0, sizeof(sg));
+            for (int q = 0; q < 3; q++) { sg.base_color[q] = f.g.base_color[q]; sg.emission[q] = f.g.emission[q]; }
+            sg.tex = f.g.tex;
+            sg.metallic = f.g.metallic;
+            sg.roughness = f.g.roughness;
+            sg.identity = f.identity;
+            memcpy(sg.m, f.m, 9 * sizeof(float));
+            flat.push_back(f);
+            shade.push_back(sg);
+            first.push_back((uint32_t)total);
+            total += c->h_prim_counts[g];
+            if (total > (1ull << 28)) return fail(c, RT3_E_UNSUPPORTED, "more than 2^28 triangles after instancing (leaf references hold 28 bits)");
+        }
+    }
+    const size_t nf = flat.size();
+    if (int r = dev_alloc(c, &c->d_geoms, nf)) return r;
+    if (int r = dev_alloc(c, &c->d_shade_geoms, nf)) return r;
+    if (int r = dev_alloc(c, &c->d_first_prim, nf)) return r;
+    if (int r = dev_alloc(c, &c->d_prim_geom, (size_t)total)) return r;
+    if (nf) {
+        HIPC(c, hipMemcpy(c->d_geoms, flat.data(), nf * sizeof(FlatGeomDev), hipMemcpyHostToDevice));
+        HIPC(c, hipMemcpy(c->d_shade_geoms, shade.data(), nf * sizeof(ShadeGeomDev), hipMemcpyHostToDevice));
+        HIPC(c, hipMemcpy(c->d_first_prim, first.data(), nf * 4, hipMemcpyHostToDevice));
+        if (nf * sizeof(FlatGeomDev) > (64u << 10)) c->bulk_copies += 3;
+        launch_prim_geom(c->stream, c->d_first_prim, (uint32_t)nf, (uint32_t)total, c->d_prim_geom);
+        HIPC(c, hipGetLastError());
+    }
+    c->n_flat_geoms = (uint32_t)nf;
+    c->n_flat_prims = (uint32_t)total;
+    return RT3_OK;
+}
+
 // ---- acceleration structure
 int rt3_accel_build(rt3_ctx* c, uint32_t* out_handle) {
     if (!c) return RT3_E_INVALID;
     HIPC(c, hipSetDevice(c->device));
     if (c->n_prims && (!c->d_verts || !c->d_indices)) return fail(c, RT3_E_STATE, "set vertices, indices and geometry before rt3_accel_build");
-    if (c->n_prims > (1u << 28)) return fail(c, RT3_E_UNSUPPORTED, "more than 2^28 triangles (leaf references hold 28 bits)");
     // the vertex / index buffers may have been replaced since rt3_scene_set_geometry checked its ranges against them
     if (int r = validate_geometry(c, c->h_geoms.data(), c->h_prim_counts.data(), (uint32_t)c->h_geoms.size())) return r;
     HIPC(c, hipStreamSynchronize(c->stream));
+    const auto t_build0 = std::chrono::steady_clock::now();
+    if (int r = flatten_world(c)) return r;
     c->accel_built = false;  // until the rebuild has succeeded: a failed one must leave RT3_E_STATE behind, not an empty tree
     dev_free(c->bvh.nodes);
     dev_free(c->bvh.tris);
     dev_free(c->bvh.tri_shade);
+    dev_free(c->bvh.tri_uv);
     dev_free(c->bvh.top);
-    hipError_t e = lbvh_build(c->stream, c->d_verts, c->d_indices, c->d_geoms, c->d_prim_geom, c->d_first_prim, c->n_prims, c->opt_leaf_size,
+    hipError_t e = lbvh_build(c->stream, c->d_verts, c->d_indices, c->d_geoms, c->d_prim_geom, c->d_first_prim, c->n_flat_prims, c->opt_leaf_size,
                               c->opt_node_width, c->opt_node_quant, c->opt_collapse, c->opt_sah_top, c->opt_sah_device, c->build_arena, &c->bvh);
     if (c->build_arena.cap > ((size_t)1 << 30)) c->build_arena.release();  // a big scene's scratch is not worth keeping resident
     if (e != hipSuccess) return fail(c, RT3_E_HIP, std::string("lbvh_build: ") + hipGetErrorString(e));
@@ -1051,10 +1126,15 @@ int rt3_accel_build(rt3_ctx* c, uint32_t* out_handle) {
         dev_free(c->bvh.nodes);
         dev_free(c->bvh.tris);
         dev_free(c->bvh.tri_shade);
+        dev_free(c->bvh.tri_uv);
         dev_free(c->bvh.top);
         return fail(c, RT3_E_DEPTH, "LBVH with " + std::to_string(c->bvh.max_depth) + " levels needs " + std::to_string(stack_need) +
                                         " stack entries, the traversal kernels hold " + std::to_string(kMaxStack));
     }
+    HIPC(c, hipStreamSynchronize(c->stream));
+    c->stats.accel_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
+    c->stats.accel_bulk_copies += c->bulk_copies + c->bvh.bulk_copies;
+    c->bulk_copies = 0;
     c->accel_built = true;
     if (out_handle) *out_handle = (RT3_TAG_ACCEL << 30) | 0u;
     return RT3_OK;

@@ -369,14 +369,46 @@ struct GeometryInfoDev {  // datatypes.slang:11-19 padded to 64 B
     uint32_t pad[3];
 };
 static_assert(sizeof(GeometryInfoDev) == 64, "GeometryInfo layout");
+// One entry per (instance, geometry) pair of the world (world/mod.rs:34-60: InstanceInfo{mesh_index, transform} + Transform{Mat4}):
+// rt3_accel_build flattens the instances into world-space triangles (the 3 ms device build stands in for the TLAS), so the builder
+// needs each pair's index / vertex offsets and its matrix, and hit_info its material and the matrix's upper 3 x 3 (hit_logic.slang:23).
+struct FlatGeomDev {
+    GeometryInfoDev g;
+    float m[12];        // column-major 3 x 4: x_axis, y_axis, z_axis, w_axis (glam Mat4 columns without their last row)
+    uint32_t identity;  // 1: the instance matrix is exactly the identity -- positions and normals are used as uploaded
+    uint32_t geom, instance, pad;
+};
+static_assert(sizeof(FlatGeomDev) == 128, "FlatGeom layout");
+// What hit_info reads of a flattened geometry, 80 bytes: k_shade keeps the whole table in LDS when it has at most kShadeGeomsLds entries
+// ("material table in LDS when <= a few hundred"), so that a hit costs ONE dependent global gather (its shading record)
+struct ShadeGeomDev {
+    float base_color[3];
+    int32_t tex;
+    float metallic, roughness;
+    float emission[3];
+    uint32_t identity;
+    float m[9];  // upper 3 x 3 of the instance matrix, column-major
+    uint32_t pad;
+};
+static_assert(sizeof(ShadeGeomDev) == 80, "ShadeGeom layout");
+constexpr uint32_t kShadeGeomsLds = 256;
+RT3_DEV V3 transform_point(const float* m, V3 p) {  // glam Mat4::transform_point3: ((x_axis * x + y_axis * y) + z_axis * z) + w_axis
+    return v3(m[9] + (m[6] * p.z + (m[3] * p.y + m[0] * p.x)), m[10] + (m[7] * p.z + (m[4] * p.y + m[1] * p.x)), m[11] + (m[8] * p.z + (m[5] * p.y + m[2] * p.x)));
+}
+RT3_DEV V3 transform_vector(const float* m9, V3 v) {  // mul(transform, float4(v, 0)).xyz, hit_logic.slang:23
+    return v3(m9[6] * v.z + (m9[3] * v.y + m9[0] * v.x), m9[7] * v.z + (m9[4] * v.y + m9[1] * v.x), m9[8] * v.z + (m9[5] * v.y + m9[2] * v.x));
+}
 
 struct SceneDev {
     const float* verts;          // interleaved p n t (8 floats)
     const uint32_t* indices;
-    const GeometryInfoDev* geoms;
+    const FlatGeomDev* geoms;    // one per (instance, geometry), in instance order
+    const ShadeGeomDev* shade_geoms;  // the same table as hit_info needs it (80-byte entries)
+    uint32_t n_geoms;
     const uint32_t* prim_geom;   // global primitive -> geometry
     const uint32_t* first_prim;  // geometry -> first global primitive
-    const float4* tri_shade;     // per global primitive, 64 B: {n0.xyz,n1.x} {n1.yz,n2.xy} {n2.z,geometry,uv0} {uv1,uv2}: one cache line
+    const uint4* tri_shade;      // per global primitive, 16 B: the three vertex normals, octahedral 2 x 16 bit each, + the flattened geometry index
+    const float2* tri_uv;        // per global primitive, 3 x float2: the vertex uvs (read only for textured geometries)
     const uint8_t* tex_pixels;   // all base-colour textures, RGBA8 (sRGB-encoded colour), back to back
     const uint4* tex_table;      // per texture {byte offset, width, height, -}
     const float* srgb_lut;       // 256 entries: sRGB EOTF
@@ -416,27 +448,57 @@ RT3_DEV V3 texture_sample(const SceneDev& sc, uint32_t index, float u, float v) 
     }
     return v3(o[0], o[1], o[2]);
 }
-// In two steps so that a caller can put independent work (the light sample's table gathers) between the issue of the
-// 64-byte shading-record loads and their use.
-struct HitRecord {
-    float4 a, b, c;
-    const float4* rec;
-};
-RT3_DEV HitRecord hit_fetch(const SceneDev& sc, uint32_t prim) {
-    const float4* rec = sc.tri_shade + 4 * (size_t)prim;
-    return HitRecord{rec[0], rec[1], rec[2], rec};
+// packing.slang:64-86: the reference's octahedral map.  Vertex normals live in the shading records through it, 16 bits per
+// coordinate (the oracle's tri_shade defines the same representation: a normal IS octa_decode16(octa_encode16(n)) on both sides).
+RT3_DEV V3 octa_decode(float fx, float fy) {  // :77-86
+    fx = fx * 2.0f - 1.0f;
+    fy = fy * 2.0f - 1.0f;
+    V3 n = v3(fx, fy, 1.0f - fabsf(fx) - fabsf(fy));
+    float t = fmin_sel(fmax_sel(-n.z, 0.0f), 1.0f);
+    n.x -= ((n.x >= 0.0f ? 1.0f : 0.0f) * 2.0f - 1.0f) * t;
+    n.y -= ((n.y >= 0.0f ? 1.0f : 0.0f) * 2.0f - 1.0f) * t;
+    return normalize(n);
 }
-RT3_DEV Surface hit_finish(const SceneDev& sc, const HitRecord& h, float bu, float bv) {
-    const float4 a = h.a, b = h.b, c = h.c;
-    const GeometryInfoDev& gi = sc.geoms[__float_as_uint(c.y)];
+RT3_DEV uint32_t octa_encode16(V3 n) {  // :64-75, then 16-bit unorm per coordinate (round to nearest); a zero vector encodes +z
+    const float s = fabsf(n.x) + fabsf(n.y) + fabsf(n.z);
+    if (!(s > 0.0f) || !(s <= 3.4028234663852886e38f)) return 0x80008000u;  // (0.5, 0.5) -> +z
+    float x = n.x / s, y = n.y / s;
+    const float z = n.z / s;
+    if (z < 0.0f) {  // octa_wrap
+        const float wx = (1.0f - fabsf(y)) * ((x >= 0.0f ? 1.0f : 0.0f) * 2.0f - 1.0f);
+        const float wy = (1.0f - fabsf(x)) * ((y >= 0.0f ? 1.0f : 0.0f) * 2.0f - 1.0f);
+        x = wx;
+        y = wy;
+    }
+    x = x * 0.5f + 0.5f;
+    y = y * 0.5f + 0.5f;
+    const uint32_t qx = (uint32_t)(fmin_sel(fmax_sel(x, 0.0f), 1.0f) * 65535.0f + 0.5f), qy = (uint32_t)(fmin_sel(fmax_sel(y, 0.0f), 1.0f) * 65535.0f + 0.5f);
+    return qx | (qy << 16);
+}
+RT3_DEV V3 octa_decode16(uint32_t w) { return octa_decode((float)(w & 0xFFFFu) * (1.0f / 65535.0f), (float)(w >> 16) * (1.0f / 65535.0f)); }
+
+// In two steps so that a caller can put independent work (the light sample's table gathers) between the issue of the
+// shading-record load and its use.  The record is 16 bytes {n0, n1, n2, geometry}: a quarter of round 2's 64-byte record, i.e.
+// a 4 MB table for 260 k triangles instead of 16.6 MB (an L2 miss costs a 128-byte line whatever the record's size).
+struct HitRecord {
+    uint4 rec;
+    uint32_t prim;
+};
+RT3_DEV HitRecord hit_fetch(const SceneDev& sc, uint32_t prim) { return HitRecord{sc.tri_shade[prim], prim}; }
+// `geoms`: the ShadeGeomDev table -- sc.shade_geoms, or the caller's LDS copy of it
+RT3_DEV Surface hit_finish(const SceneDev& sc, const ShadeGeomDev* geoms, const HitRecord& h, float bu, float bv) {
+    const ShadeGeomDev& gi = geoms[h.rec.w];
+    const V3 n0 = octa_decode16(h.rec.x), n1 = octa_decode16(h.rec.y), n2 = octa_decode16(h.rec.z);
     float b0 = 1.0f - bu - bv;
-    V3 n = v3(a.x * b0 + a.w * bu + b.z * bv, a.y * b0 + b.x * bu + b.w * bv, a.z * b0 + b.y * bu + c.x * bv);
-    n = normalize(normalize(n));  // :24 and :25
+    V3 n = v3(n0.x * b0 + n1.x * bu + n2.x * bv, n0.y * b0 + n1.y * bu + n2.y * bv, n0.z * b0 + n1.z * bu + n2.z * bv);
+    n = normalize(n);                                   // :22
+    if (!gi.identity) n = transform_vector(gi.m, n);    // :23 mul(geometryInfo.transform, float4(normal, 0.0)).xyz
+    n = normalize(n);                                   // :23
     Surface s;
     s.albedo = v3(gi.base_color[0], gi.base_color[1], gi.base_color[2]);
     if (gi.tex > -1 && (uint32_t)gi.tex < sc.n_tex) {  // :27,31-33
-        float4 e = h.rec[3];
-        float uu = c.z * b0 + e.x * bu + e.z * bv, vv = c.w * b0 + e.y * bu + e.w * bv;
+        const float2 t0 = sc.tri_uv[3 * (size_t)h.prim], t1 = sc.tri_uv[3 * (size_t)h.prim + 1], t2 = sc.tri_uv[3 * (size_t)h.prim + 2];
+        float uu = t0.x * b0 + t1.x * bu + t2.x * bv, vv = t0.y * b0 + t1.y * bu + t2.y * bv;
         s.albedo = s.albedo * texture_sample(sc, (uint32_t)gi.tex, uu, vv);
     }
     s.emissive = v3(gi.emission[0] * 12.0f, gi.emission[1] * 12.0f, gi.emission[2] * 12.0f);  // :36
@@ -445,7 +507,7 @@ RT3_DEV Surface hit_finish(const SceneDev& sc, const HitRecord& h, float bu, flo
     s.metalness = gi.metallic;
     return s;
 }
-RT3_DEV Surface hit_info(const SceneDev& sc, uint32_t prim, float bu, float bv) { return hit_finish(sc, hit_fetch(sc, prim), bu, bv); }
+RT3_DEV Surface hit_info(const SceneDev& sc, uint32_t prim, float bu, float bv) { return hit_finish(sc, sc.shade_geoms, hit_fetch(sc, prim), bu, bv); }
 
 // ------------------------------------------------------------------------------------------------ sky (north_star)
 // Texels are 8 bytes {RGB9E5 radiance, pdf_uv as f32}: the importance-sampling density of a texel travels with its colour (the

@@ -81,6 +81,7 @@ void launch_sh_conversion(hipStream_t st, uint32_t probes_x, uint32_t probes_y, 
 void launch_interpolate(hipStream_t st, const GConstDev& g, uint32_t W, uint32_t H, const void* gbuffer, const float* depth, const void* sh, void* light);
 void launch_selftest_probes(hipStream_t st, int op, const uint32_t* in, uint32_t n, uint32_t* out);
 
+void launch_prim_geom(hipStream_t st, const uint32_t* first_prim, uint32_t n_geoms, uint32_t n, uint32_t* prim_geom);
 void set_refill_lanes(uint32_t v);
 void set_pool_chunk(uint32_t v);
 void set_trace_blocks(uint32_t v);
@@ -123,12 +124,14 @@ struct LbvhResult {
     uint32_t node_bytes = 128;
     int layout = kLayoutWide128;
     float4* tris = nullptr;    // n_tris x 3 float4 (48 B), Morton order
-    float4* tri_shade = nullptr;  // n_tris x 4 float4 (64 B), global primitive order: vertex normals + geometry index
+    uint4* tri_shade = nullptr;   // n_tris x 16 B, flattened primitive order: three octahedral vertex normals + flattened geometry index
+    float2* tri_uv = nullptr;     // n_tris x 3 float2: vertex uvs
     float4* top = nullptr;     // quantised four-wide layout: the first n_top nodes in breadth-first order (64 B each), child references to
     uint32_t n_top = 0;        // cached nodes rewritten as 0x40000000 | slot -- the traversal kernels keep this copy in LDS
     uint32_t n_nodes = 0, n_tris = 0, max_depth = 0;
+    uint32_t bulk_copies = 0;  // array-sized host <-> device copies this build made (0 on the default path)
 };
-hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,
+hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indices, const FlatGeomDev* geoms, const uint32_t* prim_geom,
                       const uint32_t* first_prim, uint32_t n_prims, uint32_t leaf_max, uint32_t node_width, uint32_t node_quant, uint32_t collapse_mode,
                       uint32_t sah_top, uint32_t sah_device, BuildArena& arena, LbvhResult* out);
 

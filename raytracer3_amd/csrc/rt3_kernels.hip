@@ -675,11 +675,19 @@ struct ShadeArgs {
 };
 
 // refrence_mode.slang:28-57 for one bounce of every live path
-template <bool FIRST>
+// GLDS: the flattened-geometry table (80-byte entries, at most kShadeGeomsLds of them) is staged in LDS, so that a hit's material and
+// normal matrix cost an LDS read behind the shading record instead of a second dependent global gather
+template <bool FIRST, bool GLDS>
 // 6 waves per SIMD (80 VGPRs, 32 bytes of scratch): the kernel lives off memory-level parallelism -- 28.8 -> 27.7 ms against the
 // compiler's own choice of 93 VGPRs (4 waves with 512-thread blocks)
 __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(6, 6))) void k_shade(ShadeArgs a) {
     __shared__ uint32_t append_lds[2][2 * (kShadeBlock / 64 + 1)];  // double-buffered: see block_append2
+    __shared__ ShadeGeomDev s_geoms[GLDS ? kShadeGeomsLds : 1];
+    if (GLDS) {
+        const uint32_t words = (a.sc.n_geoms < kShadeGeomsLds ? a.sc.n_geoms : kShadeGeomsLds) * (uint32_t)(sizeof(ShadeGeomDev) / 4);
+        for (uint32_t k = threadIdx.x; k < words; k += kShadeBlock) reinterpret_cast<uint32_t*>(s_geoms)[k] = reinterpret_cast<const uint32_t*>(a.sc.shade_geoms)[k];
+        __syncthreads();
+    }
     uint32_t parity = 0;
     // the marginal sky tables (one guide word + one CDF value per row) are the first two links of every light sample's chain of
     // dependent lookups: staged in LDS they cost ~100 cycles each instead of an L1/L2 round trip
@@ -715,8 +723,8 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(6, 
         surf.metalness = 0.0f;
         uint32_t px = 0, py = 0, sample_in_batch = 0, bn = 0;
         HitRecord hrecord;
-        hrecord.a = hrecord.b = hrecord.c = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        hrecord.rec = a.sc.tri_shade;
+        hrecord.rec = make_uint4(0u, 0u, 0u, 0u);
+        hrecord.prim = 0u;
         float hbu = 0.0f, hbv = 0.0f;
         float4 ro = make_float4(0.0f, 0.0f, 0.0f, 0.0f), rd = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
         if (!FIRST && active) {  // ray records {o, pdf} + {d, path id}
@@ -799,7 +807,10 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(6, 
                 }
                 pick = sky_sample_direction(a.sc, cdf_marg, guide_marg, ul0, ul1, wl);
             }
-            if (!FIRST) surf = hit_finish(a.sc, hrecord, hbu, hbv);  // :55, second half
+            if (!FIRST) {  // :55, second half (two calls, not a selected pointer: a select would turn the LDS reads into flat loads)
+                if (GLDS) surf = hit_finish(a.sc, s_geoms, hrecord, hbu, hbv);
+                else surf = hit_finish(a.sc, a.sc.shade_geoms, hrecord, hbu, hbv);
+            }
             V3 N = surf.normal;
             if ((flags & RT3_FLAG_FACEFORWARD) && dot(N, d) > 0.0f) N = neg(N);
             if (nee) {
@@ -1052,19 +1063,27 @@ __global__ void k_selftest(int op, const uint32_t* __restrict__ in, uint32_t n, 
             out[3 * i + 2] = (uint32_t)wrap_index((int)nn, (int)(dd & 0xFFFFu) + 1);
             break;
         }
+        case 17: out[i] = octa_encode16(v3(F(in[3 * i]), F(in[3 * i + 1]), F(in[3 * i + 2]))); break;  // shading-record normals
+        case 18: {
+            const V3 n = octa_decode16(in[i]);
+            out[3 * i] = U(n.x);
+            out[3 * i + 1] = U(n.y);
+            out[3 * i + 2] = U(n.z);
+            break;
+        }
         default: break;
     }
 }
 bool selftest_widths(int op, uint32_t* in_w, uint32_t* out_w) {
-    static const uint32_t w[17][2] = {{1, 1}, {2, 1}, {2, 1}, {2, 1}, {11, 4}, {4, 11}, {2, 3}, {3, 6}, {3, 3}, {1, 2}, {2, 1}, {3, 1}, {2, 3},
-                                      {2, 3}, {3, 9}, {64, 128}, {64, 1}};
-    if (op < 0 || op > 16) return false;
+    static const uint32_t w[19][2] = {{1, 1}, {2, 1}, {2, 1}, {2, 1}, {11, 4}, {4, 11}, {2, 3}, {3, 6}, {3, 3}, {1, 2}, {2, 1}, {3, 1}, {2, 3},
+                                      {2, 3}, {3, 9}, {64, 128}, {64, 1}, {3, 1}, {1, 3}};
+    if (op < 0 || op > 18) return false;
     *in_w = w[op][0];
     *out_w = w[op][1];
     return true;
 }
 void launch_selftest(hipStream_t st, int op, const uint32_t* in, uint32_t n, uint32_t* out) {
-    if (op >= 13) return launch_selftest_probes(st, op, in, n, out);
+    if (op >= 13 && op <= 16) return launch_selftest_probes(st, op, in, n, out);
     hipLaunchKernelGGL(k_selftest, dim3((n + 255) / 256), dim3(256), 0, st, op, in, n, out);
 }
 
@@ -1165,8 +1184,9 @@ void launch_shade(hipStream_t st, bool first, const ShadeLaunch& L) {
     a.sh_rays = L.sh_rays; a.sh_contrib = L.sh_contrib; a.sh_count = L.sh_count;
     a.lacc = L.lacc; a.stride = L.stride;
     unsigned grid = grid_for(L.max_n, kShadeBlock, 8192);
-    if (first) hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(kShadeBlock), 0, st, a);
-    else hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(kShadeBlock), 0, st, a);
+    if (first) hipLaunchKernelGGL((k_shade<true, false>), dim3(grid), dim3(kShadeBlock), 0, st, a);  // the first vertex comes from the G-buffer
+    else if (a.sc.shade_geoms != nullptr && a.sc.n_geoms <= kShadeGeomsLds) hipLaunchKernelGGL((k_shade<false, true>), dim3(grid), dim3(kShadeBlock), 0, st, a);
+    else hipLaunchKernelGGL((k_shade<false, false>), dim3(grid), dim3(kShadeBlock), 0, st, a);
 }
 void launch_accumulate(hipStream_t st, const GConstDev& g, const uint32_t* pixels, uint32_t npix, uint32_t width, const float* depth,
                        const float* lacc, size_t stride, uint32_t sb, int first_batch, int last_batch, float* radsum, void* light,

@@ -35,21 +35,44 @@ __device__ __forceinline__ uint32_t float_to_ordered(float f) {
 }
 __device__ __forceinline__ float ordered_to_float(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
 
-__device__ __forceinline__ void fetch_triangle(const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,
+// The world-space triangle of flattened primitive `prim`: the vertices of its geometry under its instance's matrix (as uploaded when
+// that matrix is the identity).  Every user goes through here, so two triangles that share an edge see bit-identical end points.
+__device__ __forceinline__ void fetch_triangle(const float* verts, const uint32_t* indices, const FlatGeomDev* geoms, const uint32_t* prim_geom,
                                                const uint32_t* first_prim, uint32_t prim, V3& a, V3& b, V3& c) {
     uint32_t g = prim_geom[prim];
-    const GeometryInfoDev& gi = geoms[g];
-    uint32_t io = gi.index_offset + 3u * (prim - first_prim[g]);
-    const float* v0 = verts + 8 * (size_t)(gi.vertex_offset + indices[io]);
-    const float* v1 = verts + 8 * (size_t)(gi.vertex_offset + indices[io + 1]);
-    const float* v2 = verts + 8 * (size_t)(gi.vertex_offset + indices[io + 2]);
+    const FlatGeomDev& fg = geoms[g];
+    uint32_t io = fg.g.index_offset + 3u * (prim - first_prim[g]);
+    const float* v0 = verts + 8 * (size_t)(fg.g.vertex_offset + indices[io]);
+    const float* v1 = verts + 8 * (size_t)(fg.g.vertex_offset + indices[io + 1]);
+    const float* v2 = verts + 8 * (size_t)(fg.g.vertex_offset + indices[io + 2]);
     a = v3(v0[0], v0[1], v0[2]);
     b = v3(v1[0], v1[1], v1[2]);
     c = v3(v2[0], v2[1], v2[2]);
+    if (!fg.identity) {
+        a = transform_point(fg.m, a);
+        b = transform_point(fg.m, b);
+        c = transform_point(fg.m, c);
+    }
+}
+// flattened primitive -> flattened geometry: the last entry of first_prim (ascending, n_geoms of them) that is <= prim
+__global__ void k_prim_geom(const uint32_t* first_prim, uint32_t n_geoms, uint32_t n, uint32_t* prim_geom) {
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        uint32_t lo = 0, hi = n_geoms;  // invariant: first_prim[lo] <= p, answer in [lo, hi)
+        while (hi - lo > 1u) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (first_prim[mid] <= p) lo = mid;
+            else hi = mid;
+        }
+        prim_geom[p] = lo;
+    }
+}
+void launch_prim_geom(hipStream_t st, const uint32_t* first_prim, uint32_t n_geoms, uint32_t n, uint32_t* prim_geom) {
+    if (n == 0 || n_geoms == 0) return;
+    hipLaunchKernelGGL(k_prim_geom, dim3((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256), dim3(256), 0, st, first_prim, n_geoms, n, prim_geom);
 }
 
 // bounds[0..2] scene min, [3..5] scene max, [6..8] centroid min, [9..11] centroid max (ordered-uint encoded)
-__global__ void k_prim_bounds(const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,
+__global__ void k_prim_bounds(const float* verts, const uint32_t* indices, const FlatGeomDev* geoms, const uint32_t* prim_geom,
                               const uint32_t* first_prim, uint32_t n, float* bmin, float* bmax, uint32_t* bounds) {
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -100,20 +123,21 @@ __global__ void k_prim_bounds(const float* verts, const uint32_t* indices, const
     }
 }
 
-// shading record of hit_logic.slang:10-27: the three vertex normals, the geometry index and the three uv pairs, 64 B
-__global__ void k_tri_shade(const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,
-                            const uint32_t* first_prim, uint32_t n, float4* rec) {
+// shading record of hit_logic.slang:10-27: the three vertex normals (octahedral, 2 x 16 bit: rt3_device.hpp) + the flattened geometry
+// index, 16 B; the three uv pairs go to their own stream, which only textured geometries read
+__global__ void k_tri_shade(const float* verts, const uint32_t* indices, const FlatGeomDev* geoms, const uint32_t* prim_geom,
+                            const uint32_t* first_prim, uint32_t n, uint4* rec, float2* uv) {
     for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
         uint32_t g = prim_geom[p];
-        const GeometryInfoDev& gi = geoms[g];
+        const GeometryInfoDev& gi = geoms[g].g;
         uint32_t io = gi.index_offset + 3u * (p - first_prim[g]);
         const float* v0 = verts + 8 * (size_t)(gi.vertex_offset + indices[io]);
         const float* v1 = verts + 8 * (size_t)(gi.vertex_offset + indices[io + 1]);
         const float* v2 = verts + 8 * (size_t)(gi.vertex_offset + indices[io + 2]);
-        rec[4 * (size_t)p + 0] = make_float4(v0[3], v0[4], v0[5], v1[3]);
-        rec[4 * (size_t)p + 1] = make_float4(v1[4], v1[5], v2[3], v2[4]);
-        rec[4 * (size_t)p + 2] = make_float4(v2[5], __uint_as_float(g), v0[6], v0[7]);
-        rec[4 * (size_t)p + 3] = make_float4(v1[6], v1[7], v2[6], v2[7]);
+        rec[p] = make_uint4(octa_encode16(v3(v0[3], v0[4], v0[5])), octa_encode16(v3(v1[3], v1[4], v1[5])), octa_encode16(v3(v2[3], v2[4], v2[5])), g);
+        uv[3 * (size_t)p + 0] = make_float2(v0[6], v0[7]);
+        uv[3 * (size_t)p + 1] = make_float2(v1[6], v1[7]);
+        uv[3 * (size_t)p + 2] = make_float2(v2[6], v2[7]);
     }
 }
 
@@ -147,7 +171,7 @@ __global__ void k_morton(const float* bmin, const float* bmax, const uint32_t* b
     }
 }
 
-__global__ void k_leaves(const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,
+__global__ void k_leaves(const float* verts, const uint32_t* indices, const FlatGeomDev* geoms, const uint32_t* prim_geom,
                          const uint32_t* first_prim, const uint32_t* sorted_prim, const float* bmin, const float* bmax,
                          const uint32_t* bounds, uint32_t n, float4* tris, float* lmin, float* lmax) {
     float ex = ordered_to_float(bounds[3]) - ordered_to_float(bounds[0]);
@@ -1812,7 +1836,7 @@ sah_done:
         }                            \
     } while (0)
 
-hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indices, const GeometryInfoDev* geoms, const uint32_t* prim_geom,
+hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indices, const FlatGeomDev* geoms, const uint32_t* prim_geom,
                       const uint32_t* first_prim, uint32_t n, uint32_t leaf_max, uint32_t node_width, uint32_t node_quant, uint32_t collapse_mode,
                       uint32_t sah_top, uint32_t sah_device, BuildArena& arena, LbvhResult* out) {
     hipError_t err = hipSuccess;
@@ -1872,7 +1896,8 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
     LB_CHECK(arena.take(&levels, 4));
     LB_CHECK(hipMalloc(&out->tris, (size_t)n * 48 + 128));  // + slack: the traversal fetch may over-read the last leaf by up to 128 B
     LB_CHECK(hipMemsetAsync((char*)out->tris + (size_t)n * 48, 0, 128, st));
-    LB_CHECK(hipMalloc(&out->tri_shade, (size_t)n * 64));
+    LB_CHECK(hipMalloc(&out->tri_shade, (size_t)n * 16));
+    LB_CHECK(hipMalloc(&out->tri_uv, (size_t)n * 24));
     if (quant == 2 && n > 1) {
         LB_CHECK(arena.take(&tris_morton, (size_t)n * 48));
         LB_CHECK(arena.take(&n_int, (size_t)nn * 4));
@@ -1884,7 +1909,7 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
     LB_CHECK(hipMemsetAsync(arrive, 0, (size_t)nn * 4, st));
     LB_CHECK(hipMemsetAsync(levels, 0, 4, st));
     hipLaunchKernelGGL(k_prim_bounds, dim3(grid > 512 ? 512 : grid), dim3(256), 0, st, verts, indices, geoms, prim_geom, first_prim, n, bmin, bmax, bounds);
-    hipLaunchKernelGGL(k_tri_shade, dim3(grid), dim3(256), 0, st, verts, indices, geoms, prim_geom, first_prim, n, out->tri_shade);
+    hipLaunchKernelGGL(k_tri_shade, dim3(grid), dim3(256), 0, st, verts, indices, geoms, prim_geom, first_prim, n, out->tri_shade, out->tri_uv);
     hipLaunchKernelGGL(k_morton, dim3(grid), dim3(256), 0, st, bmin, bmax, bounds, n, keys_in, vals_in);
     LB_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, 63, st));
     LB_CHECK(arena.take(&temp, temp_bytes ? temp_bytes : 16));
@@ -1941,6 +1966,7 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
             LB_CHECK(hipMemcpyAsync(h_lmin, lmin, (size_t)n * 12, hipMemcpyDeviceToHost, st));
             LB_CHECK(hipMemcpyAsync(h_lmax, lmax, (size_t)n * 12, hipMemcpyDeviceToHost, st));
             LB_CHECK(hipMemcpyAsync(h_nbox, nbox, (size_t)nn * 24, hipMemcpyDeviceToHost, st));
+            out->bulk_copies += 8;  // the host SAH top (RT3_OPT_SAH_TOP_DEVICE = 0) is the one path that moves arrays
             LB_CHECK(hipStreamSynchronize(st));
             const auto t1 = now();
             const bool relinked = sah_top_relink(nn, h_left, h_right, h_rcnt, h_pint, h_pleaf, h_lmin, h_lmax, h_nbox, T);
@@ -1952,6 +1978,7 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
                 LB_CHECK(hipMemcpyAsync(rcnt, h_rcnt, (size_t)nn * 4, hipMemcpyHostToDevice, st));
                 LB_CHECK(hipMemcpyAsync(pint, h_pint, (size_t)nn * 4, hipMemcpyHostToDevice, st));
                 LB_CHECK(hipMemcpyAsync(pleaf, h_pleaf, (size_t)n * 4, hipMemcpyHostToDevice, st));
+                out->bulk_copies += 5;
                 LB_CHECK(hipMemsetAsync(arrive, 0, (size_t)nn * 4, st));
                 hipLaunchKernelGGL(k_refit, dim3(grid), dim3(256), 0, st, left, right, pint, pleaf, lmin, lmax, n, nbox, arrive);
                 if (trace) {
@@ -2034,12 +2061,14 @@ done:
         (void)hipFree(out->nodes);
         (void)hipFree(out->tris);
         (void)hipFree(out->tri_shade);
+        (void)hipFree(out->tri_uv);
         (void)hipFree(out->top);
         out->top = nullptr;
         out->n_top = 0;
         out->nodes = nullptr;
         out->tris = nullptr;
         out->tri_shade = nullptr;
+        out->tri_uv = nullptr;
     }
     return err;
 }

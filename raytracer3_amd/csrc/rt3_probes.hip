@@ -14,16 +14,7 @@ namespace {
 
 constexpr float kShPi = 3.1415926536f;  // spherical_harmonics.slang:4
 
-// packing.slang:77-86
-RT3_DEV V3 octa_decode(float fx, float fy) {
-    fx = fx * 2.0f - 1.0f;
-    fy = fy * 2.0f - 1.0f;
-    V3 n = v3(fx, fy, 1.0f - fabsf(fx) - fabsf(fy));
-    float t = fmin_sel(fmax_sel(-n.z, 0.0f), 1.0f);
-    n.x -= ((n.x >= 0.0f ? 1.0f : 0.0f) * 2.0f - 1.0f) * t;
-    n.y -= ((n.y >= 0.0f ? 1.0f : 0.0f) * 2.0f - 1.0f) * t;
-    return normalize(n);
-}
+// octa_decode (packing.slang:77-86): rt3_device.hpp
 // spherical_harmonics.slang:30-44 ; sh[r * 3 + c] = result[r][c]
 RT3_DEV void sh3_evaluate(V3 d, float sh[9]) {
     sh[0] = 0.28209479177387814347403972578039f;

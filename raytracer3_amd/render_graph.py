@@ -174,6 +174,15 @@ class Context:
             t = np.ascontiguousarray(t, np.uint8)
             self.check(self.lib.rt3_scene_set_texture(self.h, i, t.ctypes.data, t.shape[1], t.shape[0]))
 
+    def set_instances(self, instances):
+        """instances: [(geometry_first, geometry_count, 4x4 matrix as numpy, object -> world)] -- Instance + Transform of
+        src/renderer/world/mod.rs:46-60; [] = every geometry once under the identity.  Takes effect at the next build_accel()."""
+        arr = (L.Instance * max(1, len(instances)))()
+        for k, (first, count, m) in enumerate(instances):
+            arr[k].geometry_first, arr[k].geometry_count = int(first), int(count)
+            arr[k].transform[:] = [float(x) for x in np.asarray(m, np.float32).T.ravel()]  # column-major, like glam's Mat4
+        self.check(self.lib.rt3_scene_set_instances(self.h, C.byref(arr), len(instances)))
+
     def set_sky(self, rgb):
         s = np.ascontiguousarray(rgb, np.float32)
         self.check(self.lib.rt3_scene_set_sky(self.h, s.ctypes.data, s.shape[1], s.shape[0]))

@@ -48,6 +48,11 @@ def lib():
         L.orc_accel_set_collapse.argtypes = [vp, u32]
         L.orc_accel_set_sah_top.argtypes = [vp, u32]
         L.orc_accel_set_tree_order.argtypes = [vp, u32]
+        L.orc_scene_set_instances.argtypes = [vp, vp, u32]
+        L.orc_scene_set_instances.restype = C.c_int
+        L.orc_octa_encode16.argtypes = [vp]
+        L.orc_octa_encode16.restype = u32
+        L.orc_octa_decode16.argtypes = [u32, vp]
         L.orc_accel_node_words.restype = u32; L.orc_accel_node_words.argtypes = [vp]
         L.orc_scene_set_vertices.argtypes = [vp, vp, u32]
         L.orc_scene_set_indices.argtypes = [vp, vp, u32]
@@ -94,8 +99,11 @@ def camera_gconst(position, direction, fov_deg, width, height, z_near=0.1, z_far
     return g
 
 
+INSTANCE_DTYPE = np.dtype([("geometry_first", np.uint32), ("geometry_count", np.uint32), ("transform", np.float32, 16)])
+
+
 class Scene:
-    def __init__(self, mesh, sky=None, bluenoise=None, build=True, leaf_size=2, node_width=4, quantized=1, collapse=1, sah_top=2, tree_order=0):
+    def __init__(self, mesh, sky=None, bluenoise=None, build=True, leaf_size=2, node_width=4, quantized=1, collapse=1, sah_top=2, tree_order=0, instances=None):
         L = lib()
         self.h = L.orc_scene_create()
         L.orc_accel_set_layout(self.h, leaf_size, node_width, quantized)
@@ -108,6 +116,8 @@ class Scene:
         L.orc_scene_set_indices(self.h, ptr(i), len(i))
         g = np.ascontiguousarray(mesh.geometries); pc = np.ascontiguousarray(mesh.prim_counts, np.uint32)
         L.orc_scene_set_geometry(self.h, ptr(g), ptr(pc), len(g))
+        if instances:
+            self.set_instances(instances, build=False)
         if sky is not None:
             s = np.ascontiguousarray(sky, np.float32)
             L.orc_scene_set_sky(self.h, ptr(s), s.shape[1], s.shape[0])
@@ -119,6 +129,16 @@ class Scene:
             assert L.orc_scene_set_texture(self.h, i, ptr(t), t.shape[1], t.shape[0]) == 0
         if build:
             L.orc_accel_build(self.h)
+
+    def set_instances(self, instances, build=True):
+        """[(geometry_first, geometry_count, 4x4 object -> world)], as Context.set_instances of the product"""
+        arr = np.zeros(max(1, len(instances)), INSTANCE_DTYPE)
+        for k, (first, count, m) in enumerate(instances):
+            arr[k]["geometry_first"], arr[k]["geometry_count"] = first, count
+            arr[k]["transform"] = np.asarray(m, np.float32).T.ravel()  # column-major
+        assert lib().orc_scene_set_instances(self.h, ptr(arr), len(instances)) == 0
+        if build:
+            lib().orc_accel_build(self.h)
 
     def __del__(self):
         try:

@@ -163,22 +163,114 @@ def test_one_context_rebuilds_scenes_of_different_sizes(small, cornell):
     ctx.close()
 
 
-def test_accel_build_stays_on_the_gpu_and_fast():
-    """the default build (LBVH + device SAH top + four-wide emit) of the 260 k-triangle bench scene, second call on a
-    warm context (scratch arena in place): 3.3 ms on the box; the bound here is the review's 8 ms target, far from the 19 ms of the host SAH."""
-    import time
-
+def test_accel_build_stays_on_the_gpu():
+    """the default build (LBVH + device SAH top + four-wide emit) of the 260 k-triangle bench scene moves
+    no array between host and device -- counted by the library itself (rt3_stats.accel_bulk_copies), not inferred from a wall clock that
+    a busy box would stretch; the host SAH top (RT3_OPT_SAH_TOP_DEVICE = 0) is the path that does, and the counter sees it.  The build
+    time is reported (3 - 4 ms on an idle box), not asserted."""
     mesh = scenes.atrium(1.0)
     ctx = Context(0)
     ctx.upload_mesh(mesh)
     ctx.build_accel()
-    ts = []
-    for _ in range(5):
-        t0 = time.perf_counter()
+    ctx.stats_reset()
+    for _ in range(3):
         ctx.build_accel()
-        ts.append(1e3 * (time.perf_counter() - t0))
+    st = ctx.stats()
+    assert st.accel_bulk_copies == 0
+    assert 0.0 < st.accel_build_ms < 10_000.0
+    print(f"rt3_accel_build, {mesh.n_triangles} triangles, warm context: {st.accel_build_ms:.2f} ms")
+    ctx.set_option(L.OPT_SAH_TOP_DEVICE, 0)
+    ctx.stats_reset()
+    ctx.build_accel()
+    assert ctx.stats().accel_bulk_copies >= 8
     ctx.close()
-    assert min(ts) < 8.0, ts
+
+
+def _trs(t=(0, 0, 0), ry=0.0, s=(1, 1, 1)):
+    c, sn = math.cos(ry), math.sin(ry)
+    m = np.array([[c * s[0], 0, sn * s[2], t[0]], [0, s[1], 0, t[1]], [-sn * s[0], 0, c * s[2], t[2]], [0, 0, 0, 1]], np.float32)
+    return m
+
+
+def test_instances_two_placements_one_moved_between_frames():
+    """Instance + Transform through the ABI (world/mod.rs:46-60, hit_logic.slang:23).  A room (placed once, identity)
+    and ONE mesh placed twice under different matrices (rotation, non-uniform scale, translation); between the two frames one matrix
+    changes and the acceleration structure is rebuilt (the TLAS update).  Arrays, G-buffer and radiance of both frames bit for bit
+    against the oracle, which flattens the same instances; the build time is reported."""
+    room = scenes.cornell()
+    sky, bn = scenes.sky(128, 64), assets.load_bluenoise()
+    names = list(room.names)
+    n_room = names.index("tall")  # geometries [0, n_room) = the walls, [n_room, n_room + 2) = the two blocks
+    W, H = 112, 96
+    cam = Camera(scenes.CORNELL_CAMERA["position"], scenes.CORNELL_CAMERA["direction"], math.radians(scenes.CORNELL_CAMERA["fov_deg"]), W / H)
+    pt = PathTracer((W, H))
+    pt.ctx.upload_mesh(room)
+    pt.ctx.set_sky(sky)
+    pt.ctx.set_bluenoise(bn)
+    osc = orc.Scene(room, sky, bn, build=False)
+    m_b0 = _trs((0.9, 0.0, 0.9), 0.6, (0.5, 1.3, 0.5))
+    for frame, m_b in enumerate((m_b0, _trs((0.75, 0.25, 1.2), -0.35, (0.6, 0.9, 0.45)))):
+        inst = [(0, n_room, np.eye(4, dtype=np.float32)), (n_room, 1, _trs((0.2, 0.0, 0.1), 0.3)), (n_room, 1, m_b), (n_room + 1, 1, np.eye(4, dtype=np.float32))]
+        pt.ctx.set_instances(inst)
+        pt.ctx.stats_reset()
+        pt.ctx.build_accel()
+        build_ms = pt.ctx.stats().accel_build_ms
+        osc.set_instances(inst)
+        assert pt.ctx.accel_info()[:3] == (osc.n_nodes, osc.n_tris, osc.max_depth)
+        nodes, tris = pt.ctx.accel_download()
+        assert np.array_equal(nodes, osc.nodes()) and np.array_equal(tris, osc.tris())
+        assert osc.n_tris == room.n_triangles + int(room.prim_counts[n_room])  # the tall block's triangles twice
+        g = pt.make_gconst(cam, 8, 3, frame=frame, flags=SPEC)
+        pt.render(g)
+        light = pt.light()
+        gb, depth = pt.gbuffer()
+        og = as_orc(g)
+        ogb, odepth = osc.gbuffer(og)
+        assert np.array_equal(depth.view(np.uint32), odepth.view(np.uint32)) and np.array_equal(gb, ogb)
+        olight, _ = osc.reference_mode(og, ogb, odepth)
+        assert np.array_equal(light.view(np.uint32), olight.view(np.uint32))
+        print(f"frame {frame}: rt3_accel_build with 4 instances {build_ms:.2f} ms")
+        if frame == 0:
+            first = light.copy()
+    assert not np.array_equal(first, light)  # the moved instance shows
+    # back to the default: no instances = every geometry once under the identity = the plain scene
+    pt.ctx.set_instances([])
+    pt.ctx.build_accel()
+    plain = orc.Scene(room, sky, bn)
+    nodes, tris = pt.ctx.accel_download()
+    assert np.array_equal(nodes, plain.nodes()) and np.array_equal(tris, plain.tris())
+    # bad instances are refused, not dereferenced
+    lib = pt.ctx.lib
+    bad = (L.Instance * 1)()
+    bad[0].geometry_first, bad[0].geometry_count = 0, len(room.geometries) + 1
+    bad[0].transform[:] = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]
+    assert lib.rt3_scene_set_instances(pt.ctx.h, C.byref(bad), 1) == 0 and lib.rt3_accel_build(pt.ctx.h, None) == L.E_INVALID
+    bad[0].geometry_count = 1
+    bad[0].transform[3] = 0.5  # projective last row
+    assert lib.rt3_scene_set_instances(pt.ctx.h, C.byref(bad), 1) == L.E_INVALID
+    bad[0].transform[3] = 0.0
+    bad[0].transform[12] = float("nan")
+    assert lib.rt3_scene_set_instances(pt.ctx.h, C.byref(bad), 1) == L.E_INVALID
+    pt.close()
+
+
+def test_shading_record_normals_device_equals_oracle():
+    """The 2 x 16-bit octahedral normals of the 16-byte shading records (packing.slang:64-86): device encode / decode against the
+    oracle's on axes, octant borders, tiny / zero vectors and 4096 random directions."""
+    rng = np.random.default_rng(5)
+    n = rng.normal(size=(4096, 3)).astype(np.float32)
+    special = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [1, 1, 0], [1, 0, -1], [0, 0, 0], [1e-30, 0, 0],
+                        [1, 1, 1], [-1, -1, -1], [3e38, 3e38, 3e38]], np.float32)
+    n = np.concatenate([special, n])
+    ctx = Context(0)
+    enc = ctx.selftest(17, n.view(np.uint32), 1)[:, 0]
+    dec = ctx.selftest(18, enc.reshape(-1, 1), 3).view(np.float32)
+    ctx.close()
+    oenc = np.array([orc.lib().orc_octa_encode16(orc.ptr(np.ascontiguousarray(v))) for v in n], np.uint32)
+    odec = np.zeros((len(n), 3), np.float32)
+    for k, w in enumerate(oenc):
+        orc.lib().orc_octa_decode16(int(w), orc.ptr(odec[k]))
+    assert np.array_equal(enc, oenc) and np.array_equal(dec.view(np.uint32), odec.view(np.uint32))
 
 
 def test_lbvh_edge_cases():

@@ -159,3 +159,69 @@ def test_edge_functions_are_exactly_antisymmetric():
         L.orc_tri_edge_functions(orc.ptr(P[3]), orc.ptr(P[1]), orc.ptr(P[2]), orc.ptr(o), orc.ptr(d), orc.ptr(out3))  # U = edge (P1, P2) again
         assert out1[0] == -out2[0] and out1[0] == out3[0]
         assert (out1.view(np.uint32)[0] ^ out2.view(np.uint32)[0]) in (0x80000000, 0) or out1[0] == 0.0
+
+
+def test_instances_flatten_like_a_host_baked_mesh():
+    """rt3_scene_set_instances / orc_scene_set_instances (world/mod.rs:46-60): a mesh placed twice under two matrices is traversed exactly
+    like the mesh a host would get by transforming the positions itself with the same fp32 expression -- same triangle records, same
+    nodes, same hits -- and hit_info turns the normal by the matrix (hit_logic.slang:23)."""
+    import math
+
+    from raytracer3_amd import assets
+
+    base = scenes.cornell()
+    k = list(base.names).index("tall")
+
+    def trs(t, ry, s):
+        c, sn = math.cos(ry), math.sin(ry)
+        return np.array([[c * s[0], 0, sn * s[2], t[0]], [0, s[1], 0, t[1]], [-sn * s[0], 0, c * s[2], t[2]], [0, 0, 0, 1]], np.float32)
+
+    mats = [np.eye(4, dtype=np.float32), trs((0.5, 0.1, 1.5), 0.7, (0.5, 1.2, 0.8)), trs((-0.3, 0.0, 2.2), -1.1, (1.0, 0.5, 1.0))]
+    n_g = len(base.geometries)
+    inst = [(0, n_g, mats[0]), (k, 1, mats[1]), (k, 1, mats[2])]
+    osc = orc.Scene(base, instances=inst)
+    # the same world baked on the host: geometry k appended twice with transformed positions (normals left alone: compared separately)
+    g = base.geometries[k]
+    first = int(np.sum(base.prim_counts[:k]))
+    idx = base.indices[g["index_offset"]: g["index_offset"] + 3 * int(base.prim_counts[k])] + g["vertex_offset"]
+    verts = [base.vertices]
+    geoms = [base.geometries.copy()]
+    indices = [base.indices]
+    pcs = list(base.prim_counts)
+    for m in mats[1:]:
+        used = np.unique(idx)
+        v = base.vertices[used].copy()
+        x, y, z = v[:, 0].copy(), v[:, 1].copy(), v[:, 2].copy()
+        for r in range(3):  # glam transform_point3: w_axis + (z_axis z + (y_axis y + x_axis x)), fp32
+            v[:, r] = m[r, 3] + (m[r, 2] * z + (m[r, 1] * y + m[r, 0] * x))
+        remap = {int(u): j for j, u in enumerate(used)}
+        gi = base.geometries[k:k + 1].copy()
+        gi["vertex_offset"] = sum(len(a) for a in verts)
+        gi["index_offset"] = sum(len(a) for a in indices)
+        verts.append(v)
+        indices.append(np.array([remap[int(u)] for u in idx], np.uint32))
+        geoms.append(gi)
+        pcs.append(base.prim_counts[k])
+    baked = assets.Mesh(np.concatenate(verts), np.concatenate(indices), np.concatenate(geoms), np.array(pcs, np.uint32), list(base.names) + ["t1", "t2"])
+    ob = orc.Scene(baked)
+    assert osc.n_tris == ob.n_tris == base.n_triangles + 2 * int(base.prim_counts[k])
+    assert np.array_equal(osc.tris(), ob.tris()) and np.array_equal(osc.nodes(), ob.nodes())
+    rays = random_rays(20000, 4, [-0.9, 0.1, -0.9], [0.9, 1.9, 3.5])
+    a, b = osc.trace_closest(rays, counts=True), ob.trace_closest(rays, counts=True)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+    # normals: hit an instanced triangle and compare with M3 applied to the (quantised) object-space normal
+    t, u, v, p = a[:4]
+    sel = np.nonzero((p != 0xFFFFFFFF) & (p >= base.n_triangles))[0][:200]
+    assert len(sel) > 20
+    L = orc.lib()
+    for i in sel:
+        surf = np.zeros(11, np.float32)
+        L.orc_hit_info(osc.h, int(p[i]), float(u[i]), float(v[i]), orc.ptr(surf))
+        which = 1 if p[i] < base.n_triangles + int(base.prim_counts[k]) else 2
+        local = int(p[i]) - base.n_triangles - (which - 1) * int(base.prim_counts[k])
+        plain = np.zeros(11, np.float32)
+        L.orc_hit_info(osc.h, first + local, float(u[i]), float(v[i]), orc.ptr(plain))  # the identity placement of the same triangle (instance 0)
+        want = mats[which][:3, :3].astype(np.float64) @ plain[6:9].astype(np.float64)
+        want /= np.linalg.norm(want)
+        assert np.allclose(surf[6:9], want, atol=2e-6)
+        assert np.array_equal(surf[:6], plain[:6]) and np.array_equal(surf[9:], plain[9:])  # the material travels with the geometry

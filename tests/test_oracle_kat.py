@@ -152,3 +152,38 @@ def test_sky_alias_tables_realise_their_pdf():
     ideal = f / f.sum() * w * h
     big = ideal > 0.05
     assert np.abs(pu[big] / ideal[big] - 1.0).max() < 0.02
+
+
+def test_octahedral_normals_known_answers():
+    """packing.slang:64-86 with 16 bits per coordinate (the shading records' normals): independent numpy restatement in float64 of the
+    map's definition, exact words on the axes, and the round-trip error bound of a 16-bit grid."""
+    L = orc.lib()
+
+    def enc(v):
+        return int(L.orc_octa_encode16(orc.ptr(np.ascontiguousarray(v, np.float32))))
+
+    def dec(w):
+        o = np.zeros(3, np.float32)
+        L.orc_octa_decode16(w, orc.ptr(o))
+        return o
+
+    # +z maps to the centre (0.5, 0.5) -> 32768 on both coordinates; -z to the corners; +x to (1, 0.5); a zero vector encodes +z
+    assert enc([0, 0, 1]) == 0x80008000 and enc([0, 0, 0]) == 0x80008000
+    assert enc([1, 0, 0]) == (0x8000 << 16 | 0xFFFF) and enc([-1, 0, 0]) == (0x8000 << 16 | 0x0000)
+    assert enc([0, 1, 0]) == (0xFFFF << 16 | 0x8000) and enc([0, 0, -1]) == 0xFFFFFFFF
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for _ in range(4000):
+        n = rng.normal(size=3)
+        n /= np.linalg.norm(n)
+        # definition in float64: project to the octahedron, fold the lower hemisphere, [0, 1]^2
+        p = n / np.abs(n).sum()
+        if p[2] < 0:
+            p = np.array([(1 - abs(p[1])) * (1 if p[0] >= 0 else -1), (1 - abs(p[0])) * (1 if p[1] >= 0 else -1), p[2]])
+        q = np.floor(np.clip(p[:2] * 0.5 + 0.5, 0, 1) * 65535 + 0.5).astype(np.int64)
+        w = enc(n)
+        assert abs((w & 0xFFFF) - q[0]) <= 1 and abs((w >> 16) - q[1]) <= 1  # fp32 vs fp64 may round a tie differently
+        d = dec(w).astype(np.float64)
+        assert abs(np.linalg.norm(d) - 1) < 1e-6
+        worst = max(worst, float(np.linalg.norm(np.cross(d, n))))
+    assert worst < 8e-5, worst  # half a grid step (1.5e-5 per coordinate) on the octahedron, stretched by up to ~3 towards the sphere: 0.004 degrees
