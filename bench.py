@@ -72,10 +72,31 @@ def visible_gpus() -> int:
         return 0
 
 
+def deadline(seconds: float, what: str):
+    """A watchdog for the steps of a rank that could wait for ever on another rank (communicator bootstrap, the first exchange, a
+    collective): when the time is up the process says what it was doing and exits with status 3, so that the launcher (ours or
+    torch.distributed.run) stops the other ranks instead of the whole job sitting in a collective.  Returns the timer; .cancel() it."""
+    import threading
+
+    def fire():
+        print(f"bench.py: rank {os.environ.get('RANK', '0')}: '{what}' did not finish within {seconds:.0f} s -- giving up (exit 3)", file=sys.stderr, flush=True)
+        os._exit(3)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def self_launch(n: int, argv: list) -> int:
-    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes, relay rank 0's JSON line."""
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes, relay rank 0's JSON line.
+    The whole job has a wall-clock deadline (RT3_BENCH_DEADLINE_S, default 1500 s): past it the ranks are stopped and the exit
+    status is non-zero -- a rank stuck in a collective must not hold the caller for ever."""
     import socket
     import subprocess
+
+    limit = float(os.environ.get("RT3_BENCH_DEADLINE_S", "1500"))
+    t_start = time.monotonic()
 
     backend = os.environ.get("RT3_DIST_BACKEND", "nccl")
     ndev = visible_gpus()
@@ -92,7 +113,11 @@ def self_launch(n: int, argv: list) -> int:
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL's peer mappings need it on this driver
+        # The build environment of this pool documents: "HSA_ENABLE_IPC_MODE_LEGACY=0 is already exported here and on the GPU box -- keep it in
+        # any env you build for multi-process GPU work: the host driver only supports dmabuf IPC, and without it RCCL / CUDA-tensor sharing
+        # across processes fails with hipIpcGetMemHandle: invalid argument".  setdefault: an operator's own value wins.
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("NCCL_DEBUG", "WARN")  # RCCL's own warnings of the first exchange go to stderr with the rank's output
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
     rc = 0
@@ -118,6 +143,13 @@ def self_launch(n: int, argv: list) -> int:
                     print(f"bench.py: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
                     for q in pending:  # exact PIDs of our own children: they would wait in a collective for ever
                         procs[q].terminate()
+            if pending and time.monotonic() - t_start > limit:
+                print(f"bench.py: ranks {sorted(pending)} still running after {limit:.0f} s (RT3_BENCH_DEADLINE_S): stopping them", file=sys.stderr)
+                rc = rc or 4
+                for q in pending:
+                    procs[q].terminate()
+                time.sleep(2.0)
+                break
             time.sleep(0.05)
         th.join(timeout=5)
         js = [ln for ln in lines if ln.startswith("{")]
@@ -173,6 +205,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:  # also when a launcher other than self_launch started this rank (see self_launch for where the first one comes from)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("NCCL_DEBUG", "WARN")
+    run_watchdog = deadline(float(os.environ.get("RT3_BENCH_DEADLINE_S", "1500")), "the whole bench run") if world > 1 else None
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
     dist = None
@@ -237,14 +273,23 @@ def main():
         if backend == "nccl" or os.environ.get("RT3_TRY_RCCL"):  # (RT3_TRY_RCCL: exercise this block in the one-GPU rehearsal, where RCCL must refuse)
             # rt3_comm_init has never met more than one GPU before the driver's node: if it fails on ANY rank, every rank
             # drops to the host-moved exchange over a gloo group, and the JSON line says so -- a labelled fallback instead of no number
+            if rank == 0:
+                ver = C.c_int(0)
+                pt.ctx.lib.rt3_comm_version(C.byref(ver))
+                print(f"bench.py: RCCL (ncclGetVersion) {ver.value // 10000}.{ver.value // 100 % 100}.{ver.value % 100}, NCCL_DEBUG={os.environ.get('NCCL_DEBUG', 'unset')}, "
+                      f"HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', 'unset')}, {world} ranks", file=sys.stderr, flush=True)
+            # ncclCommInitRank blocks until every rank has joined: if one of them cannot (its own init failed, its GPU is gone), the rest
+            # would wait for ever -- the watchdog ends this rank instead, and the launcher stops the others
+            wd = deadline(float(os.environ.get("RT3_COMM_DEADLINE_S", "240")), "rt3_comm_init + agreement of the ranks")
             try:
                 pt.init_comm(uid)
                 ok, why = 1, ""
             except L.Rt3Error as e:
                 ok, why = 0, str(e)
-                print(f"bench.py: rank {rank}: rt3_comm_init failed: {why}", file=sys.stderr)
+                print(f"bench.py: rank {rank}: rt3_comm_init failed: {why}", file=sys.stderr, flush=True)
             flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            wd.cancel()
             if int(flag.item()) == 1:
                 gather_mode = "rt3_gather_tiles (RCCL)"
             else:
@@ -287,8 +332,15 @@ def main():
     pt.ctx.set_option(L.OPT_PROFILE, 0)
 
     rays_local = st.extension_rays + st.shadow_rays
+    by_rank = None
     if world > 1:
         red_dev = "cuda" if backend == "nccl" else "cpu"
+        # every rank's per-kernel HIP-event times per frame: the slowest rank decides the frame, and which kernel makes it slow is what a
+        # scaling curve needs beside it (the drain at the end of every traversal launch bounds C3 near 0.87 at N = 8)
+        mine = torch.tensor([st.extend_ms, st.shadow_ms, st.shade_ms, st.gather_ms, st.other_ms, st.trace_ms], dtype=torch.float64, device=red_dev) / max(args.steps, 1)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        by_rank = [[round(float(x), 3) for x in t.tolist()] for t in allr]
         tt = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         rr = torch.tensor([float(rays_local), float(st.extension_rays), float(st.shadow_rays)], dtype=torch.float64, device=red_dev)
@@ -320,30 +372,30 @@ def main():
     else:
         dom_name, dom_rays, dom_bytes, dom_ms, dom_launches = "k_extend", float(cst.extension_rays), ext_bytes, st.extend_ms / steps, st.extend_launches / steps
     algo_gbps = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    dom_steps = float(cst.trace_nodes[0] + cst.trace_nodes[1] + cst.trace_tris[0] + cst.trace_tris[1]) if fused else float(cst.nodes_visited + cst.tris_tested)
-    requested_gbps = (32.0 * dom_rays + 64.0 * dom_steps) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    # what the lanes REQUEST from the vector-memory path: 32 B of ray records per ray + 64 B per step (a step issues 4 x 16 B, node or
+    # triangle) -- EXCEPT the node visits the kernel serves from its LDS copy of the top of the tree (counted by the counting kernels)
+    if fused:
+        dom_nodes, dom_tris = float(cst.trace_nodes[0] + cst.trace_nodes[1]), float(cst.trace_tris[0] + cst.trace_tris[1])
+        dom_lds = float(cst.nodes_visited_lds + cst.shadow_nodes_visited_lds)
+    else:
+        dom_nodes, dom_tris, dom_lds = float(cst.nodes_visited), float(cst.tris_tested), float(cst.nodes_visited_lds)
+    requested_gbps = (32.0 * dom_rays + 64.0 * (dom_nodes - dom_lds + dom_tris)) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     trav_ms = (st.trace_ms + st.extend_ms + st.shadow_ms) / steps  # every traversal launch of the frame
     peak = 8000.0
     launches = max(dom_launches, 1)
     avg_ms = dom_ms / launches
     # ---- measured fabric-side traffic.  HBM-side bytes cannot be counted from inside this process: they come from separate
-    # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same command (tools/profile_round.sh), summarised by
-    # tools/summarize_profile.py into profiles/*_traffic.json.  Quoted only for the default workload they were collected on AND
-    # only while the kernel's average duration in that profile agrees with this run's within 5 % (a stale profile is not evidence).
+    # `rocprofv3 --pmc` passes over this same command (tools/profile_round.sh), summarised by tools/summarize_profile.py into
+    # profiles/*_traffic.json TOGETHER WITH THE HASH OF THE KERNEL SOURCES they were taken on.  A profile is quoted only for the default
+    # workload and only when that hash equals the hash of the sources this run was built from (counters of other kernels are not
+    # evidence for these, however close their times).
+    src_hash = L.kernel_source_hash()
     prof = None
-    if default_workload and world == 1:  # of the committed profiles, the newest one whose dominant-kernel time agrees with this run's
-        newest = None
+    if default_workload and world == 1:
         for tf in sorted((ROOT / "profiles").glob("r*_traffic.json")):
             tj = json.loads(tf.read_text())
-            kk = [v for k, v in tj["kernels"].items() if k.startswith(f"rt3::{dom_name}<false") and v.get("avg_ms")]
-            if not kk or avg_ms <= 0:
-                continue
-            gap = abs(kk[0]["avg_ms"] / avg_ms - 1.0)
-            # the NEWEST profile (rNN_final after rNN_base / rNN_mid, a later round after an earlier one) whose kernel time agrees with
-            # this run's within 5 %; an older one only if no newer one agrees -- equal times do not make an old code's counters current
-            age = (tf.name.split("_")[0], {"base": 0, "mid": 1}.get(tf.name.split("_")[1], 2), tf.name)
-            if gap <= 0.05 and (newest is None or age > newest):
-                newest, prof = age, dict(tj, _file=f"profiles/{tf.name}")
+            if tj.get("source_hash") == src_hash:
+                prof = dict(tj, _file=f"profiles/{tf.name}")  # (several matching files = several runs on the same kernels: the last one)
 
     def prof_kernel(prefix):
         if prof is None:
@@ -352,25 +404,25 @@ def main():
         return kk[0] if kk else None
 
     def hbm_side(entry, live_avg_ms):
-        """{traffic, traffic_raw, achieved GB/s, frac} from a profile entry, or Nones when absent / stale."""
-        if not entry or not entry.get("avg_ms") or live_avg_ms <= 0 or abs(entry["avg_ms"] / live_avg_ms - 1.0) > 0.05:
-            return {"traffic": None, "traffic_raw": None, "achieved": None, "frac": None, "stale_or_missing": True}
+        """{traffic, traffic_raw, achieved GB/s, frac} from a profile entry of THESE kernels, or Nones"""
+        if not entry or live_avg_ms <= 0:
+            return {"traffic": None, "traffic_raw": None, "achieved": None, "frac": None}
         t = entry["hbm_bytes_per_launch"]
         g = t / (live_avg_ms * 1e-3) / 1e9
         return {"traffic": round(t), "traffic_raw": round(entry["fetch_bytes_raw"] + entry["write_bytes"]), "achieved": round(g, 1), "frac": round(g / peak, 4)}
 
-    ke = hbm_side(prof_kernel(f"rt3::{dom_name}<false"), avg_ms)
-    # what the kernel MUST move through HBM whatever the caches do: its ray records in and hit records out (the queues are 24 GB)
+    pk = prof_kernel(f"rt3::{dom_name}<false") or {}
+    ke = hbm_side(pk or None, avg_ms)
+    # what the kernel MUST move through HBM whatever the caches do: its ray records in and hit records out (the queues are 21 GB)
     stream_bytes = 48.0 * dom_rays / launches
     stream_gbps = stream_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    sq = prof_kernel(f"rt3::{dom_name}<false") or {}
     binding = None
-    if sq.get("valu_per_clk_per_simd") is not None and not ke.get("stale_or_missing"):
+    if pk.get("valu_per_clk_per_simd") is not None:
         # a wave64 VALU instruction holds its SIMD-32 for two cycles: the issue ceiling is 0.5 per clock per SIMD
-        binding = {"bound": "valu_issue + vector-memory gather rate (see algorithmic.requested_GBps)", "achieved": sq["valu_per_clk_per_simd"], "peak": 0.5, "unit": "wave VALU instr / clk / SIMD",
-                   "frac": round(sq["valu_per_clk_per_simd"] / 0.5, 4), "wait_any": sq.get("wait_any"), "wait_inst_any": sq.get("wait_inst_any"),
-                   "active_inst_any": sq.get("active_inst_any"), "source": prof["_file"] if prof else None}
-    # ---- k_shade: the kernel that really is traffic bound.  Streaming bytes it must move per frame (record sizes of DESIGN.md 5):
+        binding = {"bound": "valu_issue", "achieved": pk["valu_per_clk_per_simd"], "peak": 0.5, "unit": "wave VALU instr / clk / SIMD",
+                   "frac": round(pk["valu_per_clk_per_simd"] / 0.5, 4), "wait_any": pk.get("wait_any"), "wait_inst_any": pk.get("wait_inst_any"),
+                   "active_inst_any": pk.get("active_inst_any"), "l2_hit_rate": pk.get("l2_hit_rate"), "source": prof["_file"]}
+    # ---- k_shade.  Streaming bytes it must move per frame (record sizes of DESIGN.md 5):
     # first bounce: {pixel, blue noise} 8 + depth 4 + G-buffer 16 in, radiance slot 16 out; later bounces: ray records 32 (their .w
     # carry the path's pdf and id) + throughput 12 + hit 16 in; every extension ray out 44 (ray 32 + throughput 12), every shadow ray out 40
     n_first_paths = float(W * H * args.spp) / world
@@ -378,34 +430,35 @@ def main():
     shade_stream = n_first_paths * (28.0 + 16.0) + later_in * 60.0 + float(cst.extension_rays - float(W * H) / world) * 44.0 + float(cst.shadow_rays) * 40.0
     shade_ms = st.shade_ms / steps
     shade_gbps = shade_stream / (shade_ms * 1e-3) / 1e9 if shade_ms > 0 else 0.0
-    sh_first, sh_later = prof_kernel("rt3::k_shade<true>"), prof_kernel("rt3::k_shade<false>")
+    sh_first, sh_later = prof_kernel("rt3::k_shade<true"), prof_kernel("rt3::k_shade<false")
     shade_traffic = None
-    if sh_first and sh_later and sh_first.get("avg_ms") and sh_later.get("avg_ms"):
-        prof_shade_ms = sh_first["avg_ms"] + sh_later["avg_ms"] * (args.bounces - 1)
-        if shade_ms > 0 and abs(prof_shade_ms / shade_ms - 1.0) <= 0.05:
-            shade_traffic = sh_first["hbm_bytes_per_launch"] + sh_later["hbm_bytes_per_launch"] * (args.bounces - 1)
+    if sh_first and sh_later:
+        shade_traffic = sh_first["hbm_bytes_per_launch"] + sh_later["hbm_bytes_per_launch"] * (args.bounces - 1)
+    gather_ceiling = 9650.0  # GB/s of requested bytes a pointer-chasing gather gets from any cache level (profiles/r02_gather_cap.md)
     roofline = {
-        # NOT bound by HBM (achieved / peak / frac below are its measured HBM-side share, 0.3): the walk is bound by the rate at which the
-        # memory system returns L1-missing random lines of a cache-resident 17 MB tree and by VALU issue -- see `binding`, `algorithmic`
-        "kernel": dom_name, "bound": "gather-rate + valu-issue (hbm share in frac)", "peak": peak, "unit": "GB/s",
-        # measured HBM-side (fabric) bytes of one launch / its live duration: the fraction of the HBM roofline the kernel occupies
+        "kernel": dom_name, "bound": "hbm", "peak": peak, "unit": "GB/s",
+        # frac: MEASURED fabric-side bytes of one launch (2 x FETCH_SIZE + WRITE_SIZE of a counter profile of these very kernels) / its
+        # live duration / 8 TB/s -- the share of the HBM roofline the kernel really occupies; cannot exceed 1.  Without a profile of
+        # these kernels: the compulsory queue bytes only (a lower bound), and `frac_is` says so.
         "achieved": ke["achieved"] if ke["achieved"] is not None else round(stream_gbps, 1),
         "frac": ke["frac"] if ke["frac"] is not None else round(stream_gbps / peak, 4),
-        "achieved_is": ("counter traffic (2 x FETCH_SIZE for 16 B/lane streaming reads, validated for 64 B gathers by profiles/r02_fetch_calibration.md) / live launch time"
-                        if ke["achieved"] is not None else "LOWER BOUND: compulsory queue bytes only (48 B per ray); no current counter profile for this workload"),
-        "hbm_side_frac": ke["frac"], "traffic": ke["traffic"], "traffic_uncorrected": ke["traffic_raw"], "traffic_source": prof["_file"] if (prof and ke["traffic"] is not None) else None,
+        "frac_is": ("measured fabric-side bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, same kernel sources) / live HIP-event launch time / 8 TB/s"
+                    if ke["achieved"] is not None else "LOWER BOUND: compulsory queue bytes (48 B per ray) / launch time / 8 TB/s -- no counter profile of these kernel sources is committed"),
+        "traffic": ke["traffic"], "traffic_uncorrected": ke["traffic_raw"], "traffic_source": prof["_file"] if (prof and ke["traffic"] is not None) else None,
+        # frac_8d: SURVEY 8d's contract figure -- ALGORITHMIC bytes (48 + 64 n_nodes + 48 n_tris per ray, counts equal to the oracle's) / the
+        # same launch time / 8 TB/s.  Exceeds 1 when the tree is served from L2 / Infinity Cache instead of HBM: then it measures a
+        # cache-side gather rate, not HBM use (see `vector_memory` for the ceiling that rate runs against)
+        "achieved_8d": round(algo_gbps, 1), "frac_8d": round(algo_gbps / peak, 4),
+        "frac_8d_is": f"algorithmic bytes per launch (48 + {node_bytes}*n_nodes + 48*n_tris per ray, SURVEY 8d) / live launch time / 8 TB/s; > 1 = cache-served",
+        "algorithmic_bytes_per_launch": round(dom_bytes / launches),
         "compulsory_stream": {"bytes_per_launch": round(stream_bytes), "GBps": round(stream_gbps, 1), "frac": round(stream_gbps / peak, 4)},
-        # SURVEY 8d's contract figure.  NOT an HBM fraction: the 17 MB BVH is L2 / Infinity-Cache resident, so these bytes are cache-side
-        # gathers; the comparable ceilings are the measured gather rates (MI355X_MICROARCH.md: 8.6 TB/s from the Infinity Cache,
-        # 16.8-18.8 TB/s from L2), not the 8 TB/s of HBM
-        "algorithmic": {"bytes_per_launch": round(dom_bytes / launches), "GBps": round(algo_gbps, 1), "over_hbm_peak": round(algo_gbps / peak, 4),
-                        "bytes_per_ray_formula": f"48 + {node_bytes}*n_nodes + 48*n_tris",
-                        # what the lanes REQUEST from the vector-memory path: 32 B ray + 64 B per step (a step issues 4 x 16 B, node or triangle)
-                        "requested_GBps": round(requested_gbps, 1), "gather_rate_of_the_microbenchmark_GBps": 9650.0,
-                        "ratio_to_that_rate": round(requested_gbps / 9650.0, 3),
-                        "note": "profiles/r02_gather_cap.md: a pointer-chasing gather returns at most ~9.65 TB/s of requested bytes (15.7 B/clk/CU) from any cache level; "
-                                "k_extend sits at that rate -- it, not HBM, is the memory-side ceiling of the traversal"},
+        # bytes the lanes request from the vector-memory path (LDS-served node visits excluded) against the rate a dependent gather
+        # reaches from any cache level in the microbenchmark: a fraction of THAT ceiling, <= 1
+        "vector_memory": {"requested_GBps": round(requested_gbps, 1), "ceiling_GBps": gather_ceiling, "frac": round(requested_gbps / gather_ceiling, 4),
+                          "node_visits_served_from_lds": round(dom_lds / max(dom_nodes, 1.0), 4),
+                          "is": "(32 B per ray + 64 B per node / triangle step NOT served by the LDS top-of-tree copy) / launch time, against profiles/r02_gather_cap.md"},
         "binding": binding,
+        "source_hash": src_hash,
         "launches_per_frame": dom_launches, "avg_launch_ms": round(avg_ms, 4), "rays_per_launch": round(dom_rays / launches),
         "bvh": {"nodes": n_nodes, "node_bytes": node_bytes, "tris": n_tris, "levels": levels},
         "rays_per_frame": int(cst.extension_rays), "nodes_per_ray": round(cst.nodes_visited / max(cst.extension_rays, 1), 2),
@@ -414,10 +467,12 @@ def main():
                    "tris_per_ray": round(cst.shadow_tris_tested / max(cst.shadow_rays, 1), 2)},
         "all_traversal": {"algorithmic_GBps": round((ext_bytes + sh_bytes) / max(trav_ms * 1e-3, 1e-12) / 1e9, 1), "ms_per_frame": round(trav_ms, 3),
                           "launches_per_frame": (st.trace_launches + st.extend_launches + st.shadow_launches) / steps},
-        "k_shade": {"bound": "dependent-gather latency at 6 waves per SIMD + fabric traffic (DESIGN.md 7: a sky 16 x smaller, i.e. cache resident, saves 0.6 ms of 24); hbm share in hbm_side_frac", "streaming_bytes_per_frame": round(shade_stream), "achieved": round(shade_gbps, 1), "peak": peak, "unit": "GB/s",
-                    "frac": round(shade_gbps / peak, 4), "traffic_per_frame": round(shade_traffic) if shade_traffic else None,
+        "k_shade": {"bound": "dependent-gather latency at 6 waves per SIMD (DESIGN.md 7); hbm share in hbm_side_frac", "streaming_bytes_per_frame": round(shade_stream),
+                    "achieved": round(shade_gbps, 1), "peak": peak, "unit": "GB/s", "frac": round(shade_gbps / peak, 4),
+                    "traffic_per_frame": round(shade_traffic) if shade_traffic else None,
                     "hbm_side_frac": round(shade_traffic / (shade_ms * 1e-3) / 1e9 / peak, 4) if shade_traffic else None,
-                    "traffic_over_streaming": round(shade_traffic / shade_stream, 2) if shade_traffic else None},
+                    "traffic_over_streaming": round(shade_traffic / shade_stream, 2) if shade_traffic else None,
+                    "l2_hit_rate": (sh_later or {}).get("l2_hit_rate")},
         "ms_per_frame": {"k_trace": round(st.trace_ms / steps, 3), "k_extend": round(st.extend_ms / steps, 3), "k_shadow": round(st.shadow_ms / steps, 3),
                          "k_shade": round(st.shade_ms / steps, 3), "gather": round(st.gather_ms / steps, 3), "other": round(st.other_ms / steps, 3)},
     }
@@ -425,13 +480,20 @@ def main():
     out = {
         "metric": "Mrays/s", "value": round(rays_total / dt / 1e6, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / max(args.steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic", "source_hash": src_hash,
         "config": {"workload": f"C3: atrium stand-in ({mesh.n_triangles} tris) {W}x{H}@{args.spp}spp B={args.bounces} layered BSDF (diffuse + GGX) + sky NEE/MIS + bluenoise, "
                                f"64x64 tiles over {world} GPU(s), one gather", "rays_per_frame": int(rays_total / max(args.steps, 1)), "gather": ("none" if world == 1 else gather_mode),
                    "extension_rays_per_frame": int(ext_total / max(args.steps, 1)), "shadow_rays_per_frame": int(sh_total / max(args.steps, 1)),
                    "device": pt.ctx.device_name},
         "roofline": roofline,
     }
+    if world > 1:
+        # true only when the frame's bytes moved through rt3_gather_tiles on RCCL; a FALLBACK / REHEARSAL line is NOT a measurement of the gather
+        out["gather_is_rccl"] = gather_mode.startswith("rt3_gather_tiles")
+        keys = ["k_extend", "k_shadow", "k_shade", "gather", "other", "k_trace"]
+        out["per_rank_ms_per_frame"] = {"keys": keys, "by_rank": by_rank, "max_over_ranks": {k: max(r[i] for r in by_rank) for i, k in enumerate(keys)},
+                                        "slowest_rank_sum": round(max(sum(r) for r in by_rank), 3), "mean_rank_sum": round(sum(sum(r) for r in by_rank) / world, 3),
+                                        "note": "HIP-event time of each kernel class per frame on every rank's own stream; gather = RCCL send / grouped receives (root: all peers)"}
 
     # ---- CPU baseline (rank 0, N=1 only): the oracle path-traces a centred crop of the SAME frame
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -453,9 +515,30 @@ def main():
         glight = pt.light()
         a = glight[y0:y0 + ch, x0:x0 + cw, :3].astype(np.float64)
         b = olight[y0:y0 + ch, x0:x0 + cw, :3].astype(np.float64)
-        out["cpu_baseline"] = {"value": round(crays / cdt / 1e6, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-                               "sample": f"oracle refrence_mode pass on the centred {cw}x{ch} crop of the same {W}x{H}@{args.spp}spp frame "
-                                         f"({int(crays)} rays, {cdt:.1f} s)"}
+        # SURVEY 8d's CPU baseline: the oracle's traversal of the SAME BVH arrays on the C2 primary batch (one ray per pixel) + the bounce-1
+        # batch (the extension rays of sample 0 after the first shade), all usable host threads (static split), best of 5; the GPU
+        # walks the same two batches through rt3_trace_rays for the ratio.  The crop's full path-traced pass stays beside it.
+        og1 = orc.GConst()
+        C.memmove(C.byref(og1), C.byref(og), 304)
+        fgb, fdepth = osc.gbuffer(og1, threads=threads)
+        ys_, xs_ = np.mgrid[0:H, 0:W]
+        batch = np.ascontiguousarray(np.concatenate([orc.primary_rays(og1, xs_.ravel(), ys_.ravel()), osc.bounce1_rays(og1, fgb, fdepth)], axis=1))
+        best = None
+        for _ in range(5):
+            tb = time.perf_counter()
+            ohit = osc.trace_closest(batch, threads=threads)
+            tb = time.perf_counter() - tb
+            best = tb if best is None or tb < best else best
+        ghit = pt.ctx.trace_rays(batch, repeat=5)
+        trav = {"value": round(batch.shape[1] / best / 1e6, 3), "unit": "Mrays/s", "rays": int(batch.shape[1]), "best_of_5_s": round(best, 4),
+                "gpu_same_batches_Mrays_s": round(batch.shape[1] / (ghit[4] * 1e-3) / 1e6, 1) if ghit[4] > 0 else None,
+                "gpu_hits_equal_cpu_hits": bool(np.array_equal(ghit[3], ohit[3]) and np.array_equal(ghit[0], ohit[0]))}
+        out["cpu_baseline"] = {"value": trav["value"], "unit": "Mrays/s", "cores": threads, "kind": "port",
+                               "sample": f"oracle closest-hit traversal of the bench scene's BVH arrays: the C2 primary batch ({W * H} rays) + the bounce-1 batch "
+                                         f"({batch.shape[1] - W * H} rays) at {W}x{H}, {threads} threads (static split), best of 5 = {best:.3f} s (SURVEY 8d)",
+                               "traversal": trav,
+                               "path_tracer": {"value": round(crays / cdt / 1e6, 3), "unit": "Mrays/s",
+                                               "sample": f"oracle refrence_mode pass on the centred {cw}x{ch} crop of the same {W}x{H}@{args.spp}spp frame ({int(crays)} rays, {cdt:.1f} s)"}}
         out["rmse_vs_oracle"] = float(np.sqrt(np.mean((a - b) ** 2)))
         out["crop_bit_exact"] = bool(np.array_equal(glight[y0:y0 + ch, x0:x0 + cw].view(np.uint32), olight[y0:y0 + ch, x0:x0 + cw].view(np.uint32)))
         # traversal-count cross-check: GPU counters vs oracle counters on the crop's primary rays
@@ -475,6 +558,8 @@ def main():
             solo.close()
     if rank == 0:
         print(json.dumps(out))
+    if run_watchdog is not None:
+        run_watchdog.cancel()
     pt.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -119,6 +119,8 @@ typedef struct rt3_stats {
     uint64_t trace_nodes[2];
     uint64_t trace_tris[2];
     double gather_ms; /* RCCL send / grouped receives of rt3_gather_tiles (the pack / untile kernels are in other_ms) */
+    uint64_t nodes_visited_lds;        /* of nodes_visited: served by the traversal kernels' LDS copy of the top of the tree, i.e. NOT */
+    uint64_t shadow_nodes_visited_lds; /* requested from the vector-memory path (counting mode; default node layout only) */
     double accel_build_ms;       /* host wall clock of the last rt3_accel_build, stream synchronised on both sides */
     uint64_t accel_bulk_copies;  /* host <-> device copies of array size (> 64 KiB) made by rt3_accel_build calls since rt3_stats_reset:
                                     0 on the default path (the build stays on the GPU; a few KiB of per-geometry tables go up) */
@@ -180,6 +182,12 @@ int rt3_accel_build(rt3_ctx *ctx, uint32_t *out_handle);
 /* introspection for parity tests: copy the BVH to the host (nodes: n_nodes x node_bytes (64 | 128), tris: n_tris x 48 B) */
 int rt3_accel_info(rt3_ctx *ctx, uint32_t *n_nodes, uint32_t *n_tris, uint32_t *max_depth, uint32_t *node_bytes);
 int rt3_accel_download(rt3_ctx *ctx, void *nodes, size_t nodes_bytes, void *tris, size_t tris_bytes);
+/* the way back: install a tree built elsewhere over the same (flattened) triangles -- a better offline builder, a cache of an earlier run
+ * (what vkCmdCopyMemoryToAccelerationStructureKHR is to the reference's driver).  Default layout only (64-byte nodes, 48-byte triangle
+ * records, rt3_accel_download's format); call rt3_accel_build first (it makes the shading records).  Every reference is validated on
+ * the host (range, no node reachable twice, depth) before a kernel may follow it.  Triangle records may repeat a primitive (spatial
+ * splits): the closest hit is decided by (t, prim), not by the record.  Used by tests/experiments/tree_quality_gpu.py. */
+int rt3_accel_import(rt3_ctx *ctx, const void *nodes, size_t nodes_bytes, const void *tris, size_t tris_bytes);
 /* sky tables for parity tests (any pointer may be NULL): per-row alias words q16 | alias << 16 (w*h), RGB9E5 texels (w*h),
  * marginal CDF (h), realised (u,v) density (w*h) */
 int rt3_sky_download(rt3_ctx *ctx, uint32_t *alias, uint32_t *texels_rgb9e5, float *cdf_marg, float *pdf_uv);
@@ -213,6 +221,7 @@ int rt3_image_unpack_tiles(rt3_ctx *ctx, uint32_t image, uint32_t rank, uint32_t
  *      the gloo rehearsal on a one-GPU box -- and the layout tests): offsets[r] .. offsets[r+1] is rank r's pixel range in the
  *      receive buffer (16 bytes per pixel, pixels in rt3_image_pack_tiles order, the root's range empty), n_ranks + 1 entries. ---- */
 #define RT3_COMM_ID_BYTES 128
+int rt3_comm_version(int *out); /* ncclGetVersion of the RCCL this library is linked against: major * 10000 + minor * 100 + patch */
 int rt3_comm_unique_id(void *id_out /* RT3_COMM_ID_BYTES */);
 int rt3_comm_init(rt3_ctx *ctx, const void *id /* RT3_COMM_ID_BYTES */, uint32_t rank, uint32_t n_ranks);
 int rt3_comm_destroy(rt3_ctx *ctx);

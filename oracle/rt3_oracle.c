@@ -396,6 +396,16 @@ void orc_primary_ray(const orc_gconst *g, uint32_t px, uint32_t py, float o[3], 
     o[0] = g->view_inverse[12]; o[1] = g->view_inverse[13]; o[2] = g->view_inverse[14];
 }
 
+/* orc_primary_ray for n pixels at once: 8 SoA arrays of n floats (ox oy oz dx dy dz tmin tmax) */
+void orc_primary_rays(const orc_gconst *g, const uint32_t *xs, const uint32_t *ys, uint32_t n, float tmin, float tmax, float *rays) {
+    for (uint32_t i = 0; i < n; i++) {
+        float o[3], d[3];
+        orc_primary_ray(g, xs[i], ys[i], o, d);
+        for (int k = 0; k < 3; k++) { rays[(size_t)k * n + i] = o[k]; rays[(size_t)(3 + k) * n + i] = d[k]; }
+        rays[(size_t)6 * n + i] = tmin; rays[(size_t)7 * n + i] = tmax;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------ scene */
 struct orc_scene {
     float *verts; uint32_t n_verts;      /* interleaved 8 floats */
@@ -1826,6 +1836,43 @@ static void refmode_body(void *c, uint32_t bgn, uint32_t end, int tid) {
         }
     }
     if (j->counts) { j->counts[tid][0] = n_ext; j->counts[tid][1] = n_sh; j->counts[tid][2] = n_nodes; j->counts[tid][3] = n_tris; j->counts[tid][4] = n_sh_nodes; j->counts[tid][5] = n_sh_tris; }
+}
+/* The ray batch the path tracer traces at bounce 1, sample 0 -- one extension ray per non-background pixel of the window, exactly as
+ * refmode_body would emit it at (sm 0, b 0) for g's flags -- as 8 SoA arrays of `cap` floats (ox oy oz dx dy dz tmin tmax), row-major
+ * pixel order, background pixels and ended paths skipped.  Returns the number of rays.  For the CPU-baseline leg of bench.py
+ * ("the C2 primary batch + the bounce-1 batch"). */
+uint32_t orc_bounce1_rays(const orc_scene *s, const orc_gconst *g, const uint32_t *gbuffer, const float *depth, float *rays, uint32_t cap) {
+    const uint32_t W = (uint32_t)g->window_size[0], H = (uint32_t)g->window_size[1], flags = g->pad[0], B = g->bounces;
+    const uint32_t dims = flags ? 8u : 2u;
+    const int bnz = (flags & ORC_F_BLUENOISE) && s->bn, spec = (flags & ORC_F_SPECULAR) != 0;
+    uint32_t n = 0;
+    if (B < 2) return 0;
+    for (uint32_t py = 0; py < H; py++)
+        for (uint32_t px = 0; px < W; px++) {
+            size_t pi = (size_t)py * W + px;
+            float d0 = depth[pi];
+            if (d0 == ORC_BACKGROUND_DEPTH || n >= cap) continue;
+            float surf[11], o[3], d[3];
+            orc_gbuffer_unpack(gbuffer + 4 * pi, surf);
+            orc_primary_ray(g, px, py, o, d);
+            uint32_t seed = orc_rng_seed(px, py, g->frame);
+            float u0 = orc_uniform_float(seed, 0), u1 = orc_uniform_float(seed, 1);
+            if (bnz) { const uint8_t *p = s->bn + 4 * ((size_t)(py % s->bn_h) * s->bn_w + (px % s->bn_w)); u0 = bn_shift(u0, p[0]); u1 = bn_shift(u1, p[1]); }
+            float N[3] = {surf[6], surf[7], surf[8]};
+            if ((flags & ORC_F_FACEFORWARD) && dot3(N, d) > 0.0f) { N[0] = -N[0]; N[1] = -N[1]; N[2] = -N[2]; }
+            float b1[3], b2[3], wi[3], vop[3], pdf_s, nd[3];
+            orc_onb(N, b1, b2);
+            if (spec) {
+                bsdf_t bs; bsdf_setup(surf, &bs);
+                float wo[3] = {-(d[0] * b1[0] + d[1] * b1[1] + d[2] * b1[2]), -(d[0] * b2[0] + d[1] * b2[1] + d[2] * b2[2]), -(d[0] * N[0] + d[1] * N[1] + d[2] * N[2])};
+                if (!bsdf_sample(&bs, wo, u0, u1, orc_uniform_float(seed, dims * 0u + 2u), wi, vop, &pdf_s)) continue;
+            } else orc_diffuse_sample(u0, u1, wi);
+            onb_apply(b1, b2, N, wi, nd);
+            for (int k = 0; k < 3; k++) { rays[(size_t)k * cap + n] = o[k] + d0 * d[k]; rays[(size_t)(3 + k) * cap + n] = nd[k]; }
+            rays[(size_t)6 * cap + n] = 0.001f; rays[(size_t)7 * cap + n] = ORC_BACKGROUND_DEPTH;
+            n++;
+        }
+    return n;
 }
 void orc_pass_reference_mode(const orc_scene *s, const orc_gconst *g, uint32_t x0, uint32_t y0, uint32_t x1,
                              uint32_t y1, const uint32_t *gbuffer, const float *depth, const float *prev_light,

@@ -92,6 +92,7 @@ void orc_agx_tonemap(const float in[3], float out[3]);              /* postproce
 void orc_camera_gconst(const float pos[3], const float dir[3], float fov_y, float aspect, float z_near, float z_far,
                        float width, float height, orc_gconst *out);
 void orc_primary_ray(const orc_gconst *g, uint32_t px, uint32_t py, float o[3], float d[3]); /* gbuffer_helpers.slang:85-103 */
+void orc_primary_rays(const orc_gconst *g, const uint32_t *xs, const uint32_t *ys, uint32_t n, float tmin, float tmax, float *rays); /* the same, n pixels: 8 SoA arrays */
 
 /* Instance{model} + Transform{Mat4} of the reference's world (src/renderer/world/mod.rs:34-60); == rt3_instance */
 typedef struct orc_instance {
@@ -161,6 +162,8 @@ void orc_pass_gbuffer(const orc_scene *s, const orc_gconst *g, uint32_t x0, uint
 void orc_pass_reference_mode(const orc_scene *s, const orc_gconst *g, uint32_t x0, uint32_t y0, uint32_t x1,
                              uint32_t y1, const uint32_t *gbuffer, const float *depth, const float *prev_light,
                              float *light, uint64_t *ray_counts, int n_threads);
+/* the extension rays of (sample 0, bounce 0 -> 1) for every non-background pixel, 8 SoA arrays of `cap` floats; returns their number */
+uint32_t orc_bounce1_rays(const orc_scene *s, const orc_gconst *g, const uint32_t *gbuffer, const float *depth, float *rays, uint32_t cap);
 /* postprocess.slang:90-112 ; out RGBA32F display-referred */
 void orc_pass_postprocess(const orc_scene *s, const orc_gconst *g, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1,
                           const float *depth, const float *in, float *out, int n_threads);

@@ -24,10 +24,10 @@ EXPORTS = [
     "rt3_create", "rt3_destroy", "rt3_last_error", "rt3_device_name", "rt3_set_option",
     "rt3_scene_set_vertices", "rt3_scene_set_indices", "rt3_scene_set_geometry", "rt3_scene_set_sky", "rt3_scene_set_bluenoise", "rt3_scene_set_texture",
     "rt3_scene_set_instances",
-    "rt3_accel_build", "rt3_accel_info", "rt3_accel_download", "rt3_sky_download",
+    "rt3_accel_build", "rt3_accel_info", "rt3_accel_download", "rt3_accel_import", "rt3_sky_download",
     "rt3_buffer_create", "rt3_image_create", "rt3_image_import", "rt3_resource_upload", "rt3_resource_download", "rt3_resource_device_ptr",
     "rt3_set_tile_partition", "rt3_tile_pixel_count", "rt3_image_pack_tiles", "rt3_image_unpack_tiles",
-    "rt3_comm_unique_id", "rt3_comm_init", "rt3_comm_destroy", "rt3_gather_tiles", "rt3_gather_layout", "rt3_gather_unpack",
+    "rt3_comm_version", "rt3_comm_unique_id", "rt3_comm_init", "rt3_comm_destroy", "rt3_gather_tiles", "rt3_gather_layout", "rt3_gather_unpack",
     "rt3_pass_launch", "rt3_frame_wait", "rt3_trace_rays", "rt3_selftest_eval", "rt3_stats_reset", "rt3_stats_get", "rt3_camera_gconst",
 ]
 
@@ -46,7 +46,7 @@ class Stats(C.Structure):
                 ("extend_launches", C.c_uint64), ("extend_ms", C.c_double), ("shadow_launches", C.c_uint64), ("shadow_ms", C.c_double),
                 ("shade_ms", C.c_double), ("other_ms", C.c_double),
                 ("trace_launches", C.c_uint64), ("trace_ms", C.c_double), ("trace_rays", C.c_uint64 * 2), ("trace_nodes", C.c_uint64 * 2),
-                ("trace_tris", C.c_uint64 * 2), ("gather_ms", C.c_double), ("accel_build_ms", C.c_double), ("accel_bulk_copies", C.c_uint64)]
+                ("trace_tris", C.c_uint64 * 2), ("gather_ms", C.c_double), ("nodes_visited_lds", C.c_uint64), ("shadow_nodes_visited_lds", C.c_uint64), ("accel_build_ms", C.c_double), ("accel_bulk_copies", C.c_uint64)]
 
 
 class Instance(C.Structure):
@@ -56,6 +56,19 @@ class Instance(C.Structure):
 
 
 assert C.sizeof(GConst) == 304
+
+
+def kernel_source_hash() -> str:
+    """sha256 (16 hex digits) over the sources librt3.so is built from.  tools/summarize_profile.py writes it into a counter profile,
+    bench.py quotes a profile only when it matches the tree it runs from: counters of other kernels are not evidence for these."""
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted((PKG / "csrc").glob("*.hip")) + sorted((PKG / "csrc").glob("*.hpp")) + [PKG / "csrc" / "Makefile", PKG.parent / "include" / "rt3.h"]
+    for f in files:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
 
 class Rt3Error(RuntimeError):
@@ -100,6 +113,7 @@ def load():
         "rt3_accel_build": (i32, [vp, pu32]),
         "rt3_accel_info": (i32, [vp, pu32, pu32, pu32, pu32]),
         "rt3_accel_download": (i32, [vp, vp, sz, vp, sz]),
+        "rt3_accel_import": (i32, [vp, vp, sz, vp, sz]),
         "rt3_sky_download": (i32, [vp, vp, vp, vp, vp]),
         "rt3_buffer_create": (i32, [vp, sz, pu32]),
         "rt3_image_create": (i32, [vp, u32, u32, u32, pu32]),
@@ -111,6 +125,7 @@ def load():
         "rt3_tile_pixel_count": (i32, [vp, u32, u32, pu32]),
         "rt3_image_pack_tiles": (i32, [vp, u32, u32, u32, vp]),
         "rt3_image_unpack_tiles": (i32, [vp, u32, u32, u32, vp]),
+        "rt3_comm_version": (i32, [C.POINTER(i32)]),
         "rt3_comm_unique_id": (i32, [vp]),
         "rt3_comm_init": (i32, [vp, vp, u32, u32]),
         "rt3_comm_destroy": (i32, [vp]),

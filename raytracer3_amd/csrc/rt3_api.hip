@@ -329,7 +329,7 @@ int harvest(rt3_ctx* c) {  // stream must be idle
     c->stats.extension_rays += c->primary_rays_pending;
     c->primary_rays_pending = 0;
     if (c->opt_count) {
-        unsigned long long t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [0..3] k_extend / k_shadow, [4..9] k_trace {rays, nodes, tris} x 2
+        unsigned long long t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // [0..3] k_extend / k_shadow, [4..9] k_trace {rays, nodes, tris} x 2, [10..11] node visits served by the LDS top-of-tree copy {closest, any}
         HIPC(c, hipMemcpy(t, c->d_totals, sizeof(t), hipMemcpyDeviceToHost));
         c->stats.nodes_visited += t[0] + t[5];
         c->stats.tris_tested += t[1] + t[6];
@@ -341,6 +341,8 @@ int harvest(rt3_ctx* c) {  // stream must be idle
         c->stats.trace_rays[1] += t[7];
         c->stats.trace_nodes[1] += t[8];
         c->stats.trace_tris[1] += t[9];
+        c->stats.nodes_visited_lds += t[10];
+        c->stats.shadow_nodes_visited_lds += t[11];
         HIPC(c, hipMemset(c->d_totals, 0, sizeof(t)));
     }
     for (auto& t : c->pending_events) {
@@ -685,7 +687,7 @@ int rt3_create(int device, rt3_ctx** out) {
     snprintf(c->name, sizeof(c->name), "%s (%s)", prop.name, prop.gcnArchName);
     memset(&c->stats, 0, sizeof(c->stats));
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void**)&c->d_counters, (size_t)c->counters_cap * 4) != hipSuccess ||
-        hipMalloc((void**)&c->d_totals, 80) != hipSuccess || hipMemset(c->d_totals, 0, 80) != hipSuccess) {
+        hipMalloc((void**)&c->d_totals, 96) != hipSuccess || hipMemset(c->d_totals, 0, 96) != hipSuccess) {
         delete c;
         return fail(nullptr, RT3_E_HIP, "stream / counter allocation failed");
     }
@@ -1159,6 +1161,71 @@ int rt3_accel_download(rt3_ctx* c, void* nodes, size_t nodes_bytes, void* tris, 
     }
     return RT3_OK;
 }
+// The counterpart of rt3_accel_download: install a tree somebody else built over the SAME flattened triangles (an offline builder,
+// a cache of an earlier run; Vulkan's vkCmdCopyMemoryToAccelerationStructureKHR plays this role for the reference's driver).  Default
+// layout only (64-byte quantised four-wide nodes, 48-byte triangle records).  Every reference is checked on the host before the
+// kernels may follow it: in range, no node reachable twice (so the walk terminates), depth within the traversal stack.
+int rt3_accel_import(rt3_ctx* c, const void* nodes, size_t nodes_bytes, const void* tris, size_t tris_bytes) {
+    if (!c || !nodes || !tris) return fail(c, RT3_E_INVALID, "accel_import: NULL argument");
+    if (!c->accel_built) return fail(c, RT3_E_STATE, "accel_import: build the scene's own structure first (rt3_accel_build makes the shading records)");
+    if (c->bvh.layout != kLayoutWide64Q) return fail(c, RT3_E_UNSUPPORTED, "accel_import: default node layout only");
+    if (nodes_bytes == 0 || nodes_bytes % 64 || tris_bytes % 48 || nodes_bytes / 64 > 0x3FFFFFFFull) return fail(c, RT3_E_INVALID, "accel_import: sizes must be multiples of 64 / 48 bytes");
+    const uint32_t nn = (uint32_t)(nodes_bytes / 64), nt = (uint32_t)(tris_bytes / 48);
+    const uint32_t* w = static_cast<const uint32_t*>(nodes);
+    const uint32_t* tw = static_cast<const uint32_t*>(tris);
+    for (uint32_t k = 0; k < nt; k++)
+        if (tw[12 * (size_t)k + 9] >= c->n_flat_prims) return fail(c, RT3_E_INVALID, "accel_import: triangle record " + std::to_string(k) + " names a primitive the scene does not have");
+    std::vector<uint8_t> seen(nn, 0);
+    std::vector<std::pair<uint32_t, uint32_t>> st;  // (node, level)
+    st.emplace_back(0u, 1u);
+    seen[0] = 1;
+    uint32_t max_level = 1;
+    while (!st.empty()) {
+        const auto [node, level] = st.back();
+        st.pop_back();
+        max_level = level > max_level ? level : max_level;
+        for (int k = 0; k < 4; k++) {
+            const uint32_t ref = w[16 * (size_t)node + 10 + k];
+            if (ref == 0xFFFFFFFFu) continue;
+            if (ref & 0x80000000u) {
+                const uint64_t first = ref & 0x0FFFFFFFu, cnt = ((ref >> 28) & 7u) + 1u;
+                if (first + cnt > nt) return fail(c, RT3_E_INVALID, "accel_import: node " + std::to_string(node) + " references triangles beyond the array");
+            } else {
+                if (ref >= nn || seen[ref]) return fail(c, RT3_E_INVALID, "accel_import: node " + std::to_string(node) + " references a node out of range or reachable twice");
+                seen[ref] = 1;
+                st.emplace_back(ref, level + 1);
+            }
+        }
+    }
+    const uint32_t depth = max_level + 1;  // levels from the root to the leaf slots, as lbvh_build counts them
+    if (3u * (depth - 1) > kMaxStack) return fail(c, RT3_E_DEPTH, "accel_import: the tree is deeper than the traversal stack supports");
+    HIPC(c, hipSetDevice(c->device));
+    HIPC(c, hipStreamSynchronize(c->stream));
+    float4 *d_nodes = nullptr, *d_tris = nullptr;
+    HIPC(c, hipMalloc(&d_nodes, nodes_bytes));
+    hipError_t e = hipMalloc(&d_tris, tris_bytes + 128);  // (the walk over-reads a leaf's last record by up to 128 bytes)
+    if (e == hipSuccess) e = hipMemset(d_tris, 0, tris_bytes + 128);
+    if (e == hipSuccess) e = hipMemcpy(d_nodes, nodes, nodes_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess && tris_bytes) e = hipMemcpy(d_tris, tris, tris_bytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d_nodes);
+        (void)hipFree(d_tris);
+        return fail(c, RT3_E_HIP, std::string("accel_import: ") + hipGetErrorString(e));
+    }
+    dev_free(c->bvh.nodes);
+    dev_free(c->bvh.tris);
+    c->bvh.nodes = d_nodes;
+    c->bvh.tris = d_tris;
+    c->bvh.n_nodes = nn;
+    c->bvh.n_tris = nt;
+    c->bvh.max_depth = depth;
+    e = lbvh_make_top(c->stream, c->bvh.nodes, nn, &c->bvh.top, &c->bvh.n_top);
+    if (e != hipSuccess) {
+        c->accel_built = false;
+        return fail(c, RT3_E_HIP, std::string("accel_import: top-of-tree copy: ") + hipGetErrorString(e));
+    }
+    return RT3_OK;
+}
 
 // ---- resources
 int rt3_buffer_create(rt3_ctx* c, size_t bytes, uint32_t* out) {
@@ -1340,6 +1407,11 @@ int rt3_comm_unique_id(void* id_out) {
     if (e != ncclSuccess) return fail(nullptr, RT3_E_COMM, std::string("ncclGetUniqueId: ") + ncclGetErrorString(e));
     memcpy(id_out, &id, sizeof(id));
     return RT3_OK;
+}
+int rt3_comm_version(int* out) {  // ncclGetVersion: major * 10000 + minor * 100 + patch (RCCL reports the NCCL API level it implements)
+    if (!out) return RT3_E_INVALID;
+    ncclResult_t e = ncclGetVersion(out);
+    return e == ncclSuccess ? RT3_OK : fail(nullptr, RT3_E_COMM, std::string("ncclGetVersion: ") + ncclGetErrorString(e));
 }
 int rt3_comm_init(rt3_ctx* c, const void* id, uint32_t rank, uint32_t n_ranks) {
     if (!c || !id) return fail(c, RT3_E_INVALID, "comm_init: NULL argument");

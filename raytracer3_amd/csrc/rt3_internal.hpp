@@ -135,4 +135,6 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
                       const uint32_t* first_prim, uint32_t n_prims, uint32_t leaf_max, uint32_t node_width, uint32_t node_quant, uint32_t collapse_mode,
                       uint32_t sah_top, uint32_t sah_device, BuildArena& arena, LbvhResult* out);
 
+hipError_t lbvh_make_top(hipStream_t st, const float4* nodes, uint32_t n_nodes, float4** top, uint32_t* n_top);
+
 }  // namespace rt3

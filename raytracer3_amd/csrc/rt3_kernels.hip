@@ -119,7 +119,7 @@ struct LaneRay {  // traversal state of the ray a lane currently owns
     V3 o, d, inv;
     float tmin, inv_dd;  // inv_dd = 1 / d.d (the triangle test makes no unit-length assumption)
     Hit best;
-    uint32_t cur, leaf_k, index, steps, cn, ct;
+    uint32_t cur, leaf_k, index, steps, cn, ct, cl;  // cn / ct / cl: node visits, triangle tests, node visits served by the LDS copy (COUNT)
     int sp;
     float pay0, pay1;  // shadow rays of the path tracer's own queue: two words of payload ride in the .w of the two ray records,
     float pay2, pay3;  // two more ({blue, path id}) in an 8-byte record fetched WITH the ray: at the end of the walk nothing is left to wait for
@@ -172,7 +172,7 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
     r.tmin = 0.0f;
     r.inv_dd = 1.0f;
     r.best = Hit{0.0f, 0.0f, 0.0f, kMiss};
-    r.cur = r.leaf_k = r.index = r.steps = r.cn = r.ct = 0u;
+    r.cur = r.leaf_k = r.index = r.steps = r.cn = r.ct = r.cl = 0u;
     r.sp = 0;
     r.pay0 = r.pay1 = r.pay2 = r.pay3 = 0.0f;
     r.sel_p0 = r.sel_q0 = r.sel_p1 = r.sel_q1 = 0u;
@@ -241,7 +241,7 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
                 r.sp = 0;
                 r.index = idx;
                 r.steps = 0u;
-                r.cn = r.ct = 0u;
+                r.cn = r.ct = r.cl = 0u;
                 busy = true;
                 if (MODE == 2) lane_any = second_pool;
                 // a ray with a non-finite origin or direction (NaN camera, a zero-length shading normal upstream) misses: with NaNs every
@@ -250,7 +250,7 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
                 const bool finite_ray = fabsf(r.o.x) <= kMaxF && fabsf(r.o.y) <= kMaxF && fabsf(r.o.z) <= kMaxF && fabsf(r.d.x) <= kMaxF &&
                                         fabsf(r.d.y) <= kMaxF && fabsf(r.d.z) <= kMaxF;
                 if (nodes == nullptr || !finite_ray) {  // empty scene: everything misses
-                    finish(r.index, r.best, 0u, 0u, MODE == 2 ? lane_any : MODE == 1, r.pay0, r.pay1, r.pay2, r.pay3);
+                    finish(r.index, r.best, 0u, 0u, 0u, MODE == 2 ? lane_any : MODE == 1, r.pay0, r.pay1, r.pay2, r.pay3);
                     busy = false;
                 }
             }
@@ -311,7 +311,10 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
                 pop = true;
             }
         } else {
-            if (COUNT) r.cn++;
+            if (COUNT) {
+                r.cn++;
+                r.cl += cached ? 1u : 0u;
+            }
             if (WIDE || WIDEQ) {
                 const float kInf = __builtin_huge_valf();
                 float t0, t1, t2, t3;
@@ -445,7 +448,7 @@ __device__ __forceinline__ void trace_stream(const float4* __restrict__ nodes, c
         // kMaxSteps bounds the walk so that a corrupt tree can never hang the GPU (a valid tree visits < 2 n nodes)
         if (++r.steps >= kMaxSteps) done = true;
         if (done) {
-            finish(r.index, r.best, r.cn, r.ct, MODE == 2 ? lane_any : MODE == 1, r.pay0, r.pay1, r.pay2, r.pay3);
+            finish(r.index, r.best, r.cn, r.ct, r.cl, MODE == 2 ? lane_any : MODE == 1, r.pay0, r.pay1, r.pay2, r.pay3);
             busy = false;
         }
         }  // if (busy)
@@ -460,13 +463,13 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(const float4* __restric
                                                          const uint32_t* __restrict__ count_ptr, uint32_t count_imm,
                                                          float* __restrict__ hits, uint32_t* __restrict__ cnt_nodes,
                                                          uint32_t* __restrict__ cnt_tris, unsigned long long* __restrict__ totals,
-                                                         uint32_t* __restrict__ work_counter, int payload) {
+                                                         uint32_t* __restrict__ work_counter, int payload, unsigned long long* __restrict__ lds_total) {
     __shared__ uint32_t stack[kLdsStack * kExtendBlock];
     __shared__ float4 s_top[4 * kTopNodes];
     const bool use_top = load_top(s_top, top, n_top);  // (the LDS array itself is passed on, never a selected pointer: a select would turn its reads into flat loads)
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
-    unsigned long long tot_n = 0, tot_t = 0;
-    auto finish = [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, bool, float, float, float, float) {
+    unsigned long long tot_n = 0, tot_t = 0, tot_l = 0;
+    auto finish = [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, uint32_t cl, bool, float, float, float, float) {
         // one 16-byte record per ray: with persistent waves rays finish out of order, four SoA streams would be four
         // scattered partial-line writes
         reinterpret_cast<float4*>(hits)[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
@@ -475,12 +478,14 @@ __global__ __launch_bounds__(kExtendBlock) void k_extend(const float4* __restric
             if (cnt_tris) cnt_tris[i] = ct;
             tot_n += cn;
             tot_t += ct;
+            tot_l += cl;
         }
     };
     trace_stream<0, COUNT, LAYOUT>(nodes, tris, rays, stride, n, work_counter, stack + threadIdx.x, finish, false, nullptr, 0, nullptr, payload != 0, s_top, use_top);
     if (COUNT && totals) {
         atomicAdd(&totals[0], tot_n);
         atomicAdd(&totals[1], tot_t);
+        if (lds_total) atomicAdd(lds_total, tot_l);
     }
 }
 
@@ -494,15 +499,15 @@ __global__ __launch_bounds__(kExtendBlock) void k_shadow(const float4* __restric
                                                          float* __restrict__ lacc, size_t lstride,
                                                          uint32_t* __restrict__ occluded_out, uint32_t* __restrict__ cnt_nodes,
                                                          uint32_t* __restrict__ cnt_tris, unsigned long long* __restrict__ totals,
-                                                         uint32_t* __restrict__ work_counter) {
+                                                         uint32_t* __restrict__ work_counter, unsigned long long* __restrict__ lds_total) {
     __shared__ uint32_t stack[kLdsStack * kExtendBlock];
     __shared__ float4 s_top[4 * kTopNodes];
     const bool use_top = load_top(s_top, top, n_top);  // (the LDS array itself is passed on, never a selected pointer: a select would turn its reads into flat loads)
     const uint32_t n = count_ptr ? *count_ptr : count_imm;
-    unsigned long long tot_n = 0, tot_t = 0;
+    unsigned long long tot_n = 0, tot_t = 0, tot_l = 0;
     trace_stream<1, COUNT, LAYOUT>(
         nodes, tris, rays, stride, n, work_counter, stack + threadIdx.x,
-        [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, bool, float c_r, float c_g, float c_b, float c_pid) {
+        [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, uint32_t cl, bool, float c_r, float c_g, float c_b, float c_pid) {
             if (occluded_out) {
                 occluded_out[i] = h.prim != kMiss ? 1u : 0u;
             } else if (h.prim == kMiss) {
@@ -517,12 +522,14 @@ __global__ __launch_bounds__(kExtendBlock) void k_shadow(const float4* __restric
                 if (cnt_tris) cnt_tris[i] = ct;
                 tot_n += cn;
                 tot_t += ct;
+                tot_l += cl;
             }
         },
         occluded_out == nullptr, nullptr, 0, nullptr, false, s_top, use_top, occluded_out == nullptr ? reinterpret_cast<const float2*>(contrib) : nullptr);
     if (COUNT && totals) {
         atomicAdd(&totals[0], tot_n);
         atomicAdd(&totals[1], tot_t);
+        if (lds_total) atomicAdd(lds_total, tot_l);
     }
 }
 
@@ -541,10 +548,10 @@ __global__ __launch_bounds__(kExtendBlock) void k_trace(const float4* __restrict
     __shared__ float4 s_top[4 * kTopNodes];
     const bool use_top = load_top(s_top, top, n_top);  // (the LDS array itself is passed on, never a selected pointer: a select would turn its reads into flat loads)
     const uint32_t n_ext = *ext_count, n_sh = *sh_count;
-    unsigned long long en = 0, et = 0, sn = 0, stt = 0;
+    unsigned long long en = 0, et = 0, sn = 0, stt = 0, el = 0, sl = 0;
     trace_stream<2, COUNT, LAYOUT>(
         nodes, tris, ext_rays, stride, n_ext, work_ext, stack + threadIdx.x,
-        [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, bool any, float c_r, float c_g, float c_b, float c_pid) {
+        [&](uint32_t i, const Hit& h, uint32_t cn, uint32_t ct, uint32_t cl, bool any, float c_r, float c_g, float c_b, float c_pid) {
             if (!any) {
                 reinterpret_cast<float4*>(hits)[i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.prim));
             } else if (h.prim == kMiss) {
@@ -557,6 +564,8 @@ __global__ __launch_bounds__(kExtendBlock) void k_trace(const float4* __restrict
                 et += any ? 0u : ct;
                 sn += any ? cn : 0u;
                 stt += any ? ct : 0u;
+                el += any ? 0u : cl;
+                sl += any ? cl : 0u;
             }
         },
         true, sh_rays, n_sh, work_sh, true, s_top, use_top, reinterpret_cast<const float2*>(contrib));
@@ -569,6 +578,8 @@ __global__ __launch_bounds__(kExtendBlock) void k_trace(const float4* __restrict
         atomicAdd(&totals[2], et);
         atomicAdd(&totals[4], sn);
         atomicAdd(&totals[5], stt);
+        atomicAdd(&totals[6], el);  // (= d_totals[10], [11]: node visits served by the LDS copy, closest / any)
+        atomicAdd(&totals[7], sl);
     }
 }
 
@@ -1103,7 +1114,7 @@ void launch_extend(hipStream_t st, bool count, int layout, const float4* nodes, 
     unsigned grid = grid_for(max_n, kExtendBlock, g_trace_max_blocks);
 #define RT3_LAUNCH_EXTEND(C, L)                                                                                                                  \
     hipLaunchKernelGGL((k_extend<C, L>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, top, n_top, rays, stride, count_ptr, count_imm, hits, cn, ct, totals, \
-                       work_counter, payload ? 1 : 0)
+                       work_counter, payload ? 1 : 0, totals ? totals + 10 : nullptr /* the context's totals block: [10] = LDS-served visits, closest hit */)
     if (count) {
         if (layout == kLayoutWide48Q) RT3_LAUNCH_EXTEND(true, kLayoutWide48Q);
         else if (layout == kLayoutWide64Q) RT3_LAUNCH_EXTEND(true, kLayoutWide64Q);
@@ -1123,7 +1134,7 @@ void launch_shadow(hipStream_t st, bool count, int layout, const float4* nodes, 
     unsigned grid = grid_for(max_n, kExtendBlock, g_trace_max_blocks);
 #define RT3_LAUNCH_SHADOW(C, L)                                                                                                                \
     hipLaunchKernelGGL((k_shadow<C, L>), dim3(grid), dim3(kExtendBlock), 0, st, nodes, tris, top, n_top, rays, stride, count_ptr, count_imm, contrib, pid, lacc, \
-                       lstride, occluded_out, cn, ct, totals, work_counter)
+                       lstride, occluded_out, cn, ct, totals, work_counter, totals ? totals + 9 : nullptr /* totals = block + 2 here: block[11] = LDS-served visits, any hit */)
     if (count) {
         if (layout == kLayoutWide48Q) RT3_LAUNCH_SHADOW(true, kLayoutWide48Q);
         else if (layout == kLayoutWide64Q) RT3_LAUNCH_SHADOW(true, kLayoutWide64Q);

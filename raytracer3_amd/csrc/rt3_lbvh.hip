@@ -618,6 +618,23 @@ __global__ void k_top_cache(const float4* __restrict__ nodes, uint32_t n_nodes, 
     *n_top_out = tail;
 }
 
+// (re)make the LDS top-of-tree copy for a node array in the quantised 64-byte layout (rt3_accel_import)
+hipError_t lbvh_make_top(hipStream_t st, const float4* nodes, uint32_t n_nodes, float4** top, uint32_t* n_top) {
+    *n_top = 0;
+    if (!*top) {
+        hipError_t e = hipMalloc(top, (size_t)kTopCacheNodes * 64);
+        if (e != hipSuccess) return e;
+    }
+    uint32_t* d_ntop = nullptr;
+    hipError_t e = hipMalloc(&d_ntop, 4);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_top_cache, dim3(1), dim3(1), 0, st, nodes, n_nodes, (uint32_t*)*top, d_ntop);
+    e = hipMemcpyAsync(n_top, d_ntop, 4, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_ntop);
+    return e;
+}
+
 // single-triangle scene: root with the leaf in slot 0 and empty other slots
 __global__ void k_single(const float* lmin, const float* lmax, int wide, int quant, float4* nodes) {
     const float inf = INFINITY;

@@ -196,6 +196,12 @@ class Context:
         self.check(self.lib.rt3_accel_build(self.h, C.byref(out)))
         return out.value
 
+    def accel_import(self, nodes, tris):
+        """install a tree built elsewhere over the same triangles (rt3_accel_download's format)"""
+        n = np.ascontiguousarray(nodes)
+        t = np.ascontiguousarray(tris)
+        self.check(self.lib.rt3_accel_import(self.h, n.ctypes.data, n.nbytes, t.ctypes.data, t.nbytes))
+
     def accel_info(self):
         """(n_nodes, n_tris, levels, node_bytes)"""
         a, b, c, d = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()

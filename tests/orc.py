@@ -41,6 +41,7 @@ def lib():
         L.orc_diffuse_sample.argtypes = [f32, f32, vp]
         L.orc_camera_gconst.argtypes = [vp, vp, f32, f32, f32, f32, f32, f32, vp]
         L.orc_primary_ray.argtypes = [vp, u32, u32, vp, vp]
+        L.orc_primary_rays.argtypes = [vp, vp, vp, u32, f32, f32, vp]
         L.orc_scene_create.restype = vp
         for n in ("orc_scene_destroy", "orc_accel_build"):
             getattr(L, n).argtypes = [vp]
@@ -71,6 +72,7 @@ def lib():
         L.orc_pass_gbuffer.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, C.c_int]
         L.orc_pass_reference_mode.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, vp, vp, vp, C.c_int]
         L.orc_pass_postprocess.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, vp, C.c_int]
+        L.orc_bounce1_rays.restype = u32; L.orc_bounce1_rays.argtypes = [vp, vp, vp, vp, vp, u32]
         L.orc_tile_pixels.restype = u32; L.orc_tile_pixels.argtypes = [u32, u32, u32, u32, vp]
         L.orc_octa_decode.argtypes = [f32, f32, vp]
         L.orc_sh3_evaluate.argtypes = [vp, vp]
@@ -215,6 +217,13 @@ class Scene:
         lib().orc_pass_reference_mode(self.h, C.byref(g), x0, y0, x1, y1, ptr(gb), ptr(depth), ptr(prev), ptr(light), ptr(counts), threads)
         return light, counts
 
+    def bounce1_rays(self, g, gb, depth):
+        """(8, n) float32: the extension rays the path tracer traces after the first shade of sample 0 (SURVEY 8d's bounce-1 batch)"""
+        cap = int(depth.size)
+        rays = np.zeros((8, cap), np.float32)
+        n = lib().orc_bounce1_rays(self.h, C.byref(g), ptr(gb), ptr(depth), ptr(rays), cap)
+        return np.ascontiguousarray(rays[:, :n])
+
     def postprocess(self, g, depth, img, rect=None, threads=8):
         W, H = int(g.window_size[0]), int(g.window_size[1])
         x0, y0, x1, y1 = rect or (0, 0, W, H)
@@ -259,14 +268,10 @@ def interpolate_probes(g, gb, depth, sh, light_in=None):
 
 
 def primary_rays(g, xs, ys, tmin=0.0, tmax=BACKGROUND_DEPTH):
+    xs = np.ascontiguousarray(xs, np.uint32).ravel(); ys = np.ascontiguousarray(ys, np.uint32).ravel()
     n = len(xs)
     rays = np.empty((8, n), np.float32)
-    o = (C.c_float * 3)(); d = (C.c_float * 3)()
-    L = lib()
-    for i, (x, y) in enumerate(zip(xs, ys)):
-        L.orc_primary_ray(C.byref(g), int(x), int(y), o, d)
-        rays[0:3, i] = o[:]; rays[3:6, i] = d[:]
-    rays[6] = tmin; rays[7] = tmax
+    lib().orc_primary_rays(C.byref(g), ptr(xs), ptr(ys), n, tmin, tmax, ptr(rays))
     return rays
 
 

@@ -845,7 +845,9 @@ def test_multi_rank_gather_rehearsal(tmp_path):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 3 and d["gather_bit_identical_to_single_rank"] is True and d["value"] > 0
-    assert "REHEARSAL" in d["config"]["gather"]
+    assert "REHEARSAL" in d["config"]["gather"] and d["gather_is_rccl"] is False  # host-moved bytes are never reported as the RCCL gather
+    pr = d["per_rank_ms_per_frame"]  # every rank's per-kernel times ride on the N > 1 line
+    assert len(pr["by_rank"]) == 3 and all(len(r) == len(pr["keys"]) for r in pr["by_rank"]) and pr["slowest_rank_sum"] >= pr["mean_rank_sum"] > 0
 
 
 def test_bench_falls_back_when_the_communicator_cannot_be_built():
@@ -865,7 +867,7 @@ def test_bench_falls_back_when_the_communicator_cannot_be_built():
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=500)
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert d["n_gpus"] == 2 and d["config"]["gather"].startswith("FALLBACK") and d["gather_bit_identical_to_single_rank"] is True
+    assert d["n_gpus"] == 2 and d["config"]["gather"].startswith("FALLBACK") and d["gather_bit_identical_to_single_rank"] is True and d["gather_is_rccl"] is False
     assert "rt3_comm_init failed" in r.stderr
 
 
@@ -890,7 +892,24 @@ def test_bench_default_command_prints_the_contract_line():
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["config"]["workload"].startswith("C3")
     rf = d["roofline"]
-    assert rf["unit"] == "GB/s" and 0.0 < rf["frac"] <= 1.0 and rf["achieved"] <= rf["peak"]
+    assert rf["unit"] == "GB/s" and rf["bound"] == "hbm" and 0.0 < rf["frac"] <= 1.0 and rf["achieved"] <= rf["peak"]
+    # every ratio to a ceiling is <= 1 and follows from counters of the kernels that are timed.  frac = measured fabric bytes
+    # (only from a profile whose source hash is this tree's), frac_8d = SURVEY 8d's algorithmic bytes (may exceed 1: cache-served, and says so),
+    # vector_memory.frac = requested bytes without the LDS-served node visits over the measured gather ceiling
+    from raytracer3_amd._lib import kernel_source_hash
+
+    assert d["source_hash"] == rf["source_hash"] == kernel_source_hash()
+    assert rf["frac_8d"] > 0 and "8d" in rf["frac_8d_is"].lower() and abs(rf["achieved_8d"] / rf["peak"] - rf["frac_8d"]) < 1e-3
+    vm = rf["vector_memory"]
+    assert 0.0 < vm["frac"] <= 1.0 and 0.2 < vm["node_visits_served_from_lds"] < 0.8
+    if rf["traffic"] is not None:  # quoted counters must be those of THESE kernels
+        import json as _json
+
+        prof = _json.loads((root / rf["traffic_source"]).read_text())
+        assert prof["source_hash"] == d["source_hash"] and rf["binding"]["frac"] <= 1.0
+        assert "measured" in rf["frac_is"]
+    else:
+        assert "LOWER BOUND" in rf["frac_is"] and rf["binding"] is None
     ms = rf["ms_per_frame"]
     assert abs(sum(ms.values()) - d["ms_per_step"]) < 0.05 * d["ms_per_step"]
 

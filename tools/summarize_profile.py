@@ -6,6 +6,9 @@ import csv
 import glob
 import json
 import sys
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 
 
 def short(name):
@@ -67,10 +70,34 @@ def main(src, dst):
                 lines.append(f"| `{k}` | {wc:.3g} | {v['SQ_ACTIVE_INST_ANY'] / wc:.1%} | {v['SQ_WAIT_INST_ANY'] / wc:.1%} | {v['SQ_WAIT_ANY'] / wc:.1%} | {v['SQ_INSTS_VALU']:.3g} | "
                              f"{v['SQ_INSTS_VMEM_RD']:.3g} | {t_ns / 1e6:.2f} | {use_clk:.2f} | {vpc:.3f} | {vpc / 0.5:.1%} |")
         lines.append("")
+    l2 = glob.glob(f"{src}/pmc_l2/**/*_counter_collection.csv", recursive=True)
+    l2info = {}
+    if l2:
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        for r in csv.DictReader(open(l2[0])):
+            agg[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+        lines += ["## --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum (separate pass, one frame): where the gathers are served", "",
+                  "L2 hit rate = TCC_HIT / (TCC_HIT + TCC_MISS) (MI355X_MICROARCH.md); TCP_TCC_READ_REQ = read requests that missed the CU's L1 (vector cache) and",
+                  "went to L2; TCC_EA0_RDREQ = read requests L2 sent on to the fabric (Infinity Cache / HBM).", "",
+                  "| kernel | TCC_HIT | TCC_MISS | L2 hit rate | TCP_TCC_READ_REQ | TCC_EA0_RDREQ | fabric requests per L2 read request |", "|---|---|---|---|---|---|---|"]
+        for k, v in sorted(agg.items(), key=lambda x: -(x[1].get("TCC_HIT_sum", 0.0) + x[1].get("TCC_MISS_sum", 0.0)))[:8]:
+            hit, miss = v.get("TCC_HIT_sum", 0.0), v.get("TCC_MISS_sum", 0.0)
+            if hit + miss <= 0:
+                continue
+            rq, ea = v.get("TCP_TCC_READ_REQ_sum", 0.0), v.get("TCC_EA0_RDREQ_sum", 0.0)
+            l2info[k] = {"l2_hit_rate": round(hit / (hit + miss), 4), "tcc_hit": hit, "tcc_miss": miss, "tcp_tcc_read_req": rq, "tcc_ea0_rdreq": ea}
+            lines.append(f"| `{k}` | {hit:.4g} | {miss:.4g} | {hit / (hit + miss):.1%} | {rq:.4g} | {ea:.4g} | {(ea / rq if rq else 0.0):.3f} |")
+        lines.append("")
     for log in sorted(glob.glob(f"{src}/bench*.log")):
         for ln in open(log):
             if ln.startswith("{"):
-                lines += [f"## bench line under `{log.split('/')[-1]}`", "", "```json", ln.strip(), "```", ""]
+                try:
+                    j = json.loads(ln)
+                    brief = {"value": j.get("value"), "unit": j.get("unit"), "ms_per_step": j.get("ms_per_step"), "steps": j.get("steps"),
+                             "ms_per_frame": (j.get("roofline") or {}).get("ms_per_frame"), "source_hash": j.get("source_hash")}
+                    lines += [f"## bench line under `{log.split('/')[-1]}` (per-kernel HIP events; the full line is in the matching `*_bench.log`)", "", "```json", json.dumps(brief), "```", ""]
+                except ValueError:
+                    pass
     if traffic:
         # profiles/r02_fetch_calibration.md: FETCH_SIZE tallies 64 B per 128-byte line request leaving L2, whatever the access shape
         # (coalesced streams, 16 / 64 / 128-byte random records), Infinity-Cache hits included; WRITE_SIZE is exact.  So
@@ -80,8 +107,11 @@ def main(src, dst):
             e = {"fetch_bytes_raw": v.get("FETCH_SIZE", 0.0), "write_bytes": v.get("WRITE_SIZE", 0.0),
                  "hbm_bytes_per_launch": 2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0), "avg_ms": avg_ms.get(k)}
             e.update(sqinfo.get(k, {}))
+            e.update(l2info.get(k, {}))
             out[k] = e
-        json.dump({"source": src, "correction": "2*FETCH_SIZE + WRITE_SIZE = fabric-side (L2-miss) bytes incl. Infinity-Cache hits; the factor 2 is calibrated for streams AND "
+        from raytracer3_amd._lib import kernel_source_hash
+
+        json.dump({"source": src, "source_hash": kernel_source_hash(), "correction": "2*FETCH_SIZE + WRITE_SIZE = fabric-side (L2-miss) bytes incl. Infinity-Cache hits; the factor 2 is calibrated for streams AND "
                                                 "16/64/128 B gathers in profiles/r02_fetch_calibration.md", "kernels": out}, open(dst + "_traffic.json", "w"), indent=1)
     open(dst + ".md", "w").write("\n".join(lines))
     print("wrote", dst + ".md")
