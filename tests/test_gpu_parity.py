@@ -1149,6 +1149,50 @@ def test_config_c5_progressive_accumulation_is_a_running_mean():
     assert np.allclose(acc, want, rtol=2e-6, atol=1e-7) and np.abs(acc - np.mean(singles, 0)).max() < 1e-3 * max(1.0, float(acc.max()))
 
 
+def test_config_c5_convergence_at_length_4k():
+    """configs[4] at its own size and at length, inside the GPU suite (tools/convergence.py is the 4096-spp version kept
+    under profiles/): 3840 x 2160, 16 passes of 4 spp with Light / PrevLight trading names and blendfactor 1 / (pass + 1)
+    (refrence_mode.slang:59-65), per-pixel RMSE of LINEAR radiance after 1, 2, 4, 8, 16 passes against an INDEPENDENT render (other frame
+    seeds) of 4 x the samples.  A Monte-Carlo running mean of n samples against an independent mean of N has
+    RMSE^2 = sigma^2 (1 / n + 1 / N): with the reference's own share sigma^2 / N taken off, the curve must fall by 2^-0.5 per doubling
+    (slope -0.5 +- 0.06).  And the accumulation buffer after pass 8 + the pass counter are the whole state: a fresh context loaded with
+    it reproduces passes 9 .. 16 bit for bit."""
+    W, H, spp, P, k = 3840, 2160, 4, 16, 8
+    mesh, sky, bn = scenes.atrium(1.0), scenes.sky(2048, 1024), assets.load_bluenoise()
+    cam = Camera(scenes.ATRIUM_CAMERA["position"], scenes.ATRIUM_CAMERA["direction"], math.radians(scenes.ATRIUM_CAMERA["fov_deg"]), W / H)
+
+    def progressive(first, last, seed0, per_pass_spp, start=None, keep=()):
+        pt = PathTracer((W, H))
+        pt.set_scene(mesh, sky, bn)
+        if start is not None:
+            pt.load_prev(start)
+        kept = {}
+        for p in range(first, last):
+            pt.render(pt.make_gconst(cam, per_pass_spp, 4, frame=seed0 + p, blendfactor=1.0 / (p + 1), flags=SPEC), postprocess=False, wait=False)
+            if p + 1 in keep:
+                kept[p + 1] = pt.light()
+            if p != last - 1:
+                pt.swap_light_prev()
+        img = pt.light()
+        pt.close()
+        return img, kept
+
+    marks = (1, 2, 4, 8, 16)
+    full, kept = progressive(0, P, 0, spp, keep=marks)
+    n_ref = 4 * P * spp  # 256 spp as 16 passes of 16, seeds far from the first render's
+    ref, _ = progressive(0, 16, 1000, n_ref // 16)
+    ref = ref[..., :3].astype(np.float64)
+    mse = {m: float(np.mean((kept[m][..., :3].astype(np.float64) - ref) ** 2)) for m in marks}
+    sigma2 = mse[16] / (1.0 / (16 * spp) + 1.0 / n_ref)  # per-sample variance, from the finest mark
+    own = {m: mse[m] - sigma2 / n_ref for m in marks}      # the running mean's own error, the reference's share removed
+    slopes = [0.5 * math.log2(own[b] / own[a]) for a, b in zip(marks[:-1], marks[1:])]
+    print("C5 4K: RMSE vs independent 256 spp at 4..64 spp", [round(math.sqrt(mse[m]), 4) for m in marks], "slopes per doubling", [round(x, 3) for x in slopes])
+    assert all(abs(x + 0.5) <= 0.06 for x in slopes), (slopes, mse)
+    assert np.array_equal(kept[16].view(np.uint32), full.view(np.uint32))
+    resumed, _ = progressive(k, P, 0, spp, start=kept[k])
+    assert np.array_equal(resumed.view(np.uint32), full.view(np.uint32)) and full[..., :3].mean() > 0
+
+
 def test_progressive_restart_from_a_dumped_accumulation_buffer(small):
     """SURVEY 5 (checkpoint / resume) for BASELINE configs[4]: the accumulation buffer after pass k plus the pass counter are the whole
     state of a progressive render -- a fresh context loaded with that buffer as PrevLight reproduces the remaining passes bit for bit
