@@ -36,7 +36,7 @@ import time
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
-DEFAULT_SAH_TOP = 2  # the library's RT3_OPT_SAH_TOP default (the oracle of the parity leg is built the same way)
+DEFAULT_SAH_TOP = 1  # the library's RT3_OPT_SAH_TOP default (the oracle of the parity leg is built the same way)
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 

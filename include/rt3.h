@@ -142,10 +142,12 @@ int rt3_device_name(rt3_ctx *ctx, char *buf, size_t buf_size);
 #define RT3_OPT_LEAF_SIZE 5       /* 1..8 triangles per BVH leaf (default 2); takes effect at the next rt3_accel_build */
 #define RT3_OPT_NODE_WIDTH 6      /* 2 = binary nodes, 4 = four-wide nodes (default); next rt3_accel_build */
 #define RT3_OPT_NODE_QUANT 7      /* width 4 only: 1 = 64 B nodes with 8-bit conservative child boxes (default), 0 = 128 B fp32 boxes, 2 = compact 48 B nodes (implied references) */
-#define RT3_OPT_WIDE_COLLAPSE 8   /* width 4 only: how binary LBVH nodes are grouped into four-wide nodes: 1 = by surface area (default), 0 = even binary depth */
+#define RT3_OPT_WIDE_COLLAPSE 8   /* width 4 only: how the binary tree becomes four-wide nodes: 2 = cost-driven (default since round 3: a bottom-up SAH dynamic
+                                     programme also decides which subtrees become multi-triangle leaves; triangle records in tree order), 1 = greedy by surface
+                                     area, 0 = even binary depth */
 #define RT3_OPT_POOL_CHUNK 9      /* traversal tuning: rays a wave takes from the launch's ray pool per grab (default 256) */
 #define RT3_OPT_FUSED_TRACE 10    /* 1: one k_trace launch per bounce walks the extension queue and then the shadow queue; 0 (default): separate k_shadow and k_extend launches */
-#define RT3_OPT_SAH_TOP 11       /* T > 0 (default 2): the tree above Karras subtrees of at most T triangles is re-linked by binned SAH
+#define RT3_OPT_SAH_TOP 11       /* T > 0 (default 1 = binned SAH down to single triangles; collapse 0 / 1 use max(T, leaf size)): the tree above Karras subtrees of at most T triangles is re-linked by binned SAH
                                      (the reference asks its driver for PREFER_FAST_TRACE builds, raytracing.rs:103,131); 0 = plain LBVH */
 #define RT3_OPT_TRACE_BLOCKS 12   /* traversal tuning: persistent workgroups (256 threads) per traversal launch (default 2048 = 8 per CU) */
 #define RT3_OPT_SAH_TOP_DEVICE 13  /* 1 (default): the SAH top is built on the GPU, no bulk copies; 0: on the host (same tree, bit for bit) */

@@ -438,8 +438,8 @@ orc_scene *orc_scene_create(void) {
     s->leaf_max = 2;
     s->node_width = 4;
     s->node_quant = 1;
-    s->collapse = 1;
-    s->sah_top = 2;
+    s->collapse = 2; /* cost-driven collapse over a binned-SAH tree down to single triangles (round 3) */
+    s->sah_top = 1;
     for (int i = 0; i < 256; i++) { /* sRGB EOTF, IEC 61966-2-1, in double */
         double c = i / 255.0;
         s->srgb_lut[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));

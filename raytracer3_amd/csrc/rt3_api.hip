@@ -120,7 +120,7 @@ struct rt3_ctx {
     int64_t opt_batch_spp = 0;
     bool opt_profile = false, opt_count = false;
     int opt_variant = 0;  // RT3_OPT_EXTEND_VARIANT: reserved for traversal experiments
-    uint32_t opt_leaf_size = 2, opt_node_width = 4, opt_node_quant = 1, opt_collapse = 1, opt_sah_top = 2, opt_sah_device = 1;
+    uint32_t opt_leaf_size = 2, opt_node_width = 4, opt_node_quant = 1, opt_collapse = 2, opt_sah_top = 1, opt_sah_device = 1;
     int opt_fused_trace = 0;  // 1: k_trace (extension + shadow queue in one launch per bounce)
     rt3_stats stats;
     uint64_t primary_rays_pending = 0;
@@ -774,7 +774,7 @@ int rt3_set_option(rt3_ctx* c, int option, int64_t value) {
             set_trace_blocks((uint32_t)value);
             return RT3_OK;
         case RT3_OPT_WIDE_COLLAPSE:
-            if (value != 0 && value != 1) return fail(c, RT3_E_INVALID, "wide collapse must be 0 (even depth) or 1 (surface area)");
+            if (value < 0 || value > 2) return fail(c, RT3_E_INVALID, "wide collapse must be 0 (even depth), 1 (surface area) or 2 (cost-driven)");
             c->opt_collapse = (uint32_t)value;
             c->accel_built = false;
             return RT3_OK;

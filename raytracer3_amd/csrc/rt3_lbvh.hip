@@ -308,7 +308,7 @@ __global__ void k_refit_clusters(const uint32_t* range_lo, const uint32_t* range
 
 // binary depth (root = 0) by walking the parents; keep[i] = 1 if node i survives into the traversal array:
 // it covers more than leaf_max triangles (or is the root) and, for four-wide nodes, sits at an even depth.
-__global__ void k_keep_flags(const uint32_t* parent_internal, const uint32_t* range_cnt, uint32_t nn, uint32_t leaf_max, int wide,
+__global__ void k_keep_flags(const uint32_t* parent_internal, const uint32_t* live_f, uint32_t nn, int wide,
                              uint32_t* keep, uint32_t* max_levels) {
     uint32_t best = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += gridDim.x * blockDim.x) {
@@ -317,7 +317,7 @@ __global__ void k_keep_flags(const uint32_t* parent_internal, const uint32_t* ra
             d++;
             p = parent_internal[p];
         }
-        bool live = i == 0 || range_cnt[i] > leaf_max;
+        bool live = live_f[i] != 0u;
         bool k = live && (!wide || (d & 1u) == 0u);
         keep[i] = k ? 1u : 0u;
         if (k) {
@@ -329,7 +329,7 @@ __global__ void k_keep_flags(const uint32_t* parent_internal, const uint32_t* ra
 }
 
 __device__ __forceinline__ void slot_of(uint32_t ch, const float* lmin, const float* lmax, const float* nbox, const uint32_t* range_lo,
-                                        const uint32_t* range_cnt, const uint32_t* newidx, uint32_t leaf_max, float mn[3], float mx[3], uint32_t& ref) {
+                                        const uint32_t* range_cnt, const uint32_t* newidx, const uint32_t* live, float mn[3], float mx[3], uint32_t& ref) {
     if (ch & 0x80000000u) {
         uint32_t q = ch & 0x7FFFFFFFu;
         ref = 0x80000000u | q;
@@ -344,8 +344,9 @@ __device__ __forceinline__ void slot_of(uint32_t ch, const float* lmin, const fl
             mn[j] = nbox[6 * (size_t)ch + j];
             mx[j] = nbox[6 * (size_t)ch + 3 + j];
         }
-        bool live = range_cnt[ch] > leaf_max;  // ch != 0: the root is nobody's child
-        ref = live ? newidx[ch] : (0x80000000u | ((range_cnt[ch] - 1u) << 28) | range_lo[ch]);
+        // live[ch]: the node stays a node (it covers more than leaf_max triangles, or the cost-driven collapse decided so); otherwise
+        // it is referenced as a multi-triangle leaf over its range
+        ref = live[ch] ? newidx[ch] : (0x80000000u | ((range_cnt[ch] - 1u) << 28) | range_lo[ch]);
     }
 }
 
@@ -430,13 +431,154 @@ __device__ void compact_node(const float (*mn)[3], const float (*mx)[3], const u
         out[k] = make_float4(__uint_as_float(w[4 * k]), __uint_as_float(w[4 * k + 1]), __uint_as_float(w[4 * k + 2]), __uint_as_float(w[4 * k + 3]));
 }
 
+// live[i] = node i stays a node of the traversal array (collapse 0 / 1: it is the root or covers more than leaf_max triangles)
+__global__ void k_live_flags(const uint32_t* range_cnt, uint32_t nn, uint32_t leaf_max, uint32_t* live) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += gridDim.x * blockDim.x) live[i] = (i == 0u || range_cnt[i] > leaf_max) ? 1u : 0u;
+}
+
+// ---- cost-driven collapse (RT3_OPT_WIDE_COLLAPSE = 2; the oracle's orc_accel_build has the recurrences, after Ylitie, Karras, Laine 2017):
+// bottom-up over the final binary tree -- a leaf starts at its parent, the second arrival at a node computes it from its two children --
+//   C(n,1) = min( A_n cnt_n [a leaf of <= leaf_max triangles],  A_n + D(n,4) [a four-wide node] ),  C(n,m) = min( D(n,m), C(n,m-1) ),
+//   D(n,j) = min over 0 < k < j of C(left,k) + C(right,j-k),  C(triangle,.) = A,
+// fp32, the oracle's order, strict '<'.  Also writes the TRUE triangle count of every node (range_cnt) and live[] (not a leaf).
+// dk bits: 0-1 k of D(n,4); 2 k of D(n,3) minus 1; 3 C(n,1) is a leaf; 4 C(n,2) = D(n,2); 5 C(n,3) = D(n,3).
+__device__ __forceinline__ float half_area_box(const float* mn, const float* mx) {
+    const float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
+    return (ex * ey + ey * ez) + ez * ex;
+}
+__global__ void k_dp_up(const uint32_t* left, const uint32_t* right, const uint32_t* parent_internal, const uint32_t* parent_leaf, const float* lmin,
+                        const float* lmax, const float* nbox, uint32_t n, uint32_t leaf_max, uint32_t* range_cnt, float* dc, uint32_t* dk, uint32_t* live,
+                        uint32_t* arrive) {
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+        uint32_t cur = parent_leaf[q];
+        while (cur != 0xFFFFFFFFu) {
+            __threadfence();
+            const uint32_t prev = atomicAdd(&arrive[cur], 1u);
+            if (prev == 0u) break;  // first arrival: the sibling subtree is not finished yet
+            __threadfence();
+            const uint32_t ch[2] = {left[cur], right[cur]};
+            float C[2][3];
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                if (ch[c] & 0x80000000u) {
+                    const uint32_t t = ch[c] & 0x7FFFFFFFu;
+                    const float a = half_area_box(lmin + 3 * (size_t)t, lmax + 3 * (size_t)t);
+                    C[c][0] = C[c][1] = C[c][2] = a;
+                    cnt += 1u;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 3; j++) C[c][j] = __hip_atomic_load(&dc[3 * (size_t)ch[c] + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cnt += __hip_atomic_load(&range_cnt[ch[c]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            const float d2 = C[0][0] + C[1][0];
+            float d3 = C[0][0] + C[1][1];
+            uint32_t k3 = 1;
+            {
+                const float b = C[0][1] + C[1][0];
+                if (b < d3) { d3 = b; k3 = 2; }
+            }
+            float d4 = C[0][0] + C[1][2];
+            uint32_t k4 = 1;
+            {
+                float b = C[0][1] + C[1][1];
+                if (b < d4) { d4 = b; k4 = 2; }
+                b = C[0][2] + C[1][0];
+                if (b < d4) { d4 = b; k4 = 3; }
+            }
+            const float A = half_area_box(nbox + 6 * (size_t)cur, nbox + 6 * (size_t)cur + 3);
+            const float cint = A + d4, cleaf = (float)cnt * A;
+            const uint32_t leaf1 = (cur != 0u && cnt <= leaf_max && cleaf <= cint) ? 1u : 0u;
+            const float c1 = leaf1 ? cleaf : cint;
+            const uint32_t s2 = d2 < c1 ? 1u : 0u;
+            const float c2 = s2 ? d2 : c1;
+            const uint32_t s3 = d3 < c2 ? 1u : 0u;
+            const float c3 = s3 ? d3 : c2;
+            __hip_atomic_store(&dc[3 * (size_t)cur], c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&dc[3 * (size_t)cur + 1], c2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&dc[3 * (size_t)cur + 2], c3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&range_cnt[cur], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            dk[cur] = k4 | ((k3 - 1u) << 2) | (leaf1 << 3) | (s2 << 4) | (s3 << 5);
+            live[cur] = leaf1 ? 0u : 1u;
+            cur = parent_internal[cur];
+        }
+    }
+}
+// TREE ORDER: the position of a triangle (the first triangle of a node) in the depth-first order of the final binary tree = the sum, over
+// the ancestors it hangs under on the RIGHT, of the triangle count of their left child.  One walk to the root per leaf / node, no
+// synchronisation; every subtree becomes a contiguous range (so any node may be referenced as a multi-triangle leaf).
+__device__ __forceinline__ uint32_t tree_position(uint32_t me_ref, uint32_t parent, const uint32_t* left, const uint32_t* right, const uint32_t* parent_internal,
+                                                  const uint32_t* range_cnt) {
+    uint32_t pos = 0;
+    while (parent != 0xFFFFFFFFu) {
+        if (right[parent] == me_ref) {
+            const uint32_t l = left[parent];
+            pos += (l & 0x80000000u) ? 1u : range_cnt[l];
+        }
+        me_ref = parent;
+        parent = parent_internal[parent];
+    }
+    return pos;
+}
+__global__ void k_tree_order(const uint32_t* left, const uint32_t* right, const uint32_t* parent_internal, const uint32_t* parent_leaf, const uint32_t* range_cnt,
+                             uint32_t n, uint32_t nn, uint32_t* newpos, uint32_t* range_lo) {
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n + nn; t += gridDim.x * blockDim.x) {
+        if (t < n) newpos[t] = tree_position(0x80000000u | t, parent_leaf[t], left, right, parent_internal, range_cnt);
+        else range_lo[t - n] = tree_position(t - n, parent_internal[t - n], left, right, parent_internal, range_cnt);
+    }
+}
+// move the triangle records and leaf boxes to their tree-order places; rewrite the leaf references of the links
+__global__ void k_tree_reorder(const uint32_t* newpos, uint32_t n, uint32_t nn, const float4* tris_in, float4* tris_out, const float* lmin_in, const float* lmax_in,
+                               float* lmin_out, float* lmax_out, uint32_t* left, uint32_t* right) {
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n + nn; t += gridDim.x * blockDim.x) {
+        if (t < n) {
+            const uint32_t p = newpos[t];
+#pragma unroll
+            for (int k = 0; k < 3; k++) tris_out[3 * (size_t)p + k] = tris_in[3 * (size_t)t + k];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                lmin_out[3 * (size_t)p + j] = lmin_in[3 * (size_t)t + j];
+                lmax_out[3 * (size_t)p + j] = lmax_in[3 * (size_t)t + j];
+            }
+        } else {
+            const uint32_t i = t - n, l = left[i], r = right[i];
+            if (l & 0x80000000u) left[i] = 0x80000000u | newpos[l & 0x7FFFFFFFu];
+            if (r & 0x80000000u) right[i] = 0x80000000u | newpos[r & 0x7FFFFFFFu];
+        }
+    }
+}
+
 // child slots of surviving node i, in tree order.  Four-wide nodes, collapse 0 (even binary depth): a child that is itself
 // a live internal node is absorbed (its two children take its place).  Collapse 1 (surface area, default): the two child
 // slots are grown to (up to) four by repeatedly replacing the live internal slot of largest surface area by its two
 // children (ties: first slot); half area = (ex*ey + ey*ez) + ez*ex in fp32, like the oracle.
-__device__ __forceinline__ uint32_t gather_slots(uint32_t i, const uint32_t* left, const uint32_t* right, const uint32_t* range_cnt,
-                                                 const float* nbox, uint32_t leaf_max, int wide, int collapse, uint32_t sl[4]) {
+// Collapse 2 (cost-driven, default since round 3): the choices k_dp_up recorded in dk are unfolded top-down, left subtree's slots first
+// (the oracle's dp_slots).
+__device__ __forceinline__ uint32_t gather_slots(uint32_t i, const uint32_t* left, const uint32_t* right, const uint32_t* live,
+                                                 const float* nbox, const uint32_t* dk, int wide, int collapse, uint32_t sl[4]) {
     uint32_t ns = 0;
+    if (wide && collapse == 2) {
+        uint32_t sn[8], sm[8];
+        int sp = 0;
+        const uint32_t k4 = dk[i] & 3u;
+        sl[0] = sl[1] = sl[2] = sl[3] = 0xFFFFFFFFu;
+        sn[sp] = right[i]; sm[sp++] = 4u - k4;
+        sn[sp] = left[i]; sm[sp++] = k4;
+        while (sp > 0) {
+            const uint32_t nd = sn[--sp];
+            uint32_t m = sm[sp];
+            if (nd & 0x80000000u) { sl[ns++] = nd; continue; }
+            const uint32_t f = dk[nd];
+            if (m == 3u && !(f & 32u)) m = 2u;
+            if (m == 2u && !(f & 16u)) m = 1u;
+            if (m == 1u) { sl[ns++] = nd; continue; }
+            const uint32_t kl = m == 2u ? 1u : ((f >> 2) & 1u) + 1u;
+            sn[sp] = right[nd]; sm[sp++] = m - kl;
+            sn[sp] = left[nd]; sm[sp++] = kl;
+        }
+        return ns;
+    }
     if (wide && collapse) {
         ns = 2;
         sl[0] = left[i];
@@ -447,7 +589,7 @@ __device__ __forceinline__ uint32_t gather_slots(uint32_t i, const uint32_t* lef
             float ba = -1.0f;
             for (uint32_t k = 0; k < ns; k++) {
                 const uint32_t ch = sl[k];
-                if ((ch & 0x80000000u) || range_cnt[ch] <= leaf_max) continue;
+                if ((ch & 0x80000000u) || !live[ch]) continue;
                 const float ex = nbox[6 * (size_t)ch + 3] - nbox[6 * (size_t)ch], ey = nbox[6 * (size_t)ch + 4] - nbox[6 * (size_t)ch + 1],
                             ez = nbox[6 * (size_t)ch + 5] - nbox[6 * (size_t)ch + 2];
                 const float a = (ex * ey + ey * ez) + ez * ex;
@@ -469,7 +611,7 @@ __device__ __forceinline__ uint32_t gather_slots(uint32_t i, const uint32_t* lef
 #pragma unroll
     for (int c = 0; c < 2; c++) {
         const uint32_t ch = c2[c];
-        if (wide && !(ch & 0x80000000u) && range_cnt[ch] > leaf_max) {
+        if (wide && !(ch & 0x80000000u) && live[ch]) {
             sl[ns++] = left[ch];
             sl[ns++] = right[ch];
         } else {
@@ -482,30 +624,30 @@ __device__ __forceinline__ uint32_t gather_slots(uint32_t i, const uint32_t* lef
 
 // surface-area collapse, one four-wide level per launch: every node of the frontier survives; its live internal slots
 // form the next frontier
-__global__ void k_wide_level(const uint32_t* left, const uint32_t* right, const uint32_t* range_cnt, const float* nbox, uint32_t leaf_max,
+__global__ void k_wide_level(const uint32_t* left, const uint32_t* right, const uint32_t* live, const float* nbox, const uint32_t* dk, int collapse,
                              const uint32_t* frontier, const uint32_t* n_frontier_ptr, uint32_t* keep, uint32_t* next, uint32_t* n_next) {
     const uint32_t n_frontier = *n_frontier_ptr;  // written by the level before: levels are launched back to back, no host round trip
     for (uint32_t f = blockIdx.x * blockDim.x + threadIdx.x; f < n_frontier; f += gridDim.x * blockDim.x) {
         const uint32_t i = frontier[f];
         keep[i] = 1u;
         uint32_t sl[4];
-        const uint32_t ns = gather_slots(i, left, right, range_cnt, nbox, leaf_max, 1, 1, sl);
+        const uint32_t ns = gather_slots(i, left, right, live, nbox, dk, 1, collapse, sl);
         for (uint32_t k = 0; k < ns; k++)
-            if (!(sl[k] & 0x80000000u) && range_cnt[sl[k]] > leaf_max) next[atomicAdd(n_next, 1u)] = sl[k];
+            if (!(sl[k] & 0x80000000u) && live[sl[k]]) next[atomicAdd(n_next, 1u)] = sl[k];
     }
 }
 
 // compact layout, pass 1: per surviving node the number of internal child slots and of triangles in leaf slots
 __global__ void k_child_counts(const uint32_t* left, const uint32_t* right, const uint32_t* range_cnt, const float* nbox, const uint32_t* keep, uint32_t nn,
-                               uint32_t leaf_max, int collapse, uint32_t* n_internal, uint32_t* n_leaf_tris) {
+                               const uint32_t* live, const uint32_t* dk, int collapse, uint32_t* n_internal, uint32_t* n_leaf_tris) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += gridDim.x * blockDim.x) {
         uint32_t ci = 0, ti = 0;
         if (keep[i]) {
             uint32_t sl[4];
-            const uint32_t ns = gather_slots(i, left, right, range_cnt, nbox, leaf_max, 1, collapse, sl);
+            const uint32_t ns = gather_slots(i, left, right, live, nbox, dk, 1, collapse, sl);
             for (uint32_t k = 0; k < ns; k++) {
                 if (sl[k] & 0x80000000u) ti += 1u;
-                else if (range_cnt[sl[k]] > leaf_max) ci += 1u;
+                else if (live[sl[k]]) ci += 1u;
                 else ti += range_cnt[sl[k]];
             }
         }
@@ -514,27 +656,27 @@ __global__ void k_child_counts(const uint32_t* left, const uint32_t* right, cons
     }
 }
 // compact layout, pass 2 (after the exclusive sums): a child's index is 1 + node_base(parent) + rank among the internal slots
-__global__ void k_assign_index(const uint32_t* left, const uint32_t* right, const uint32_t* range_cnt, const float* nbox, const uint32_t* keep, uint32_t nn,
-                               uint32_t leaf_max, int collapse, const uint32_t* cbase, uint32_t* newidx) {
+__global__ void k_assign_index(const uint32_t* left, const uint32_t* right, const uint32_t* live, const float* nbox, const uint32_t* keep, uint32_t nn,
+                               const uint32_t* dk, int collapse, const uint32_t* cbase, uint32_t* newidx) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += gridDim.x * blockDim.x) {
         if (i == 0) newidx[0] = 0u;
         if (!keep[i]) continue;
         uint32_t sl[4], rank = 0;
-        const uint32_t ns = gather_slots(i, left, right, range_cnt, nbox, leaf_max, 1, collapse, sl);
+        const uint32_t ns = gather_slots(i, left, right, live, nbox, dk, 1, collapse, sl);
         for (uint32_t k = 0; k < ns; k++)
-            if (!(sl[k] & 0x80000000u) && range_cnt[sl[k]] > leaf_max) newidx[sl[k]] = 1u + cbase[i] + rank++;
+            if (!(sl[k] & 0x80000000u) && live[sl[k]]) newidx[sl[k]] = 1u + cbase[i] + rank++;
     }
 }
 
 // one thread per surviving node: gather its 2 (binary) or 2..4 (wide: internal children are absorbed) child slots
 __global__ void k_emit_nodes(const uint32_t* left, const uint32_t* right, const uint32_t* range_lo, const uint32_t* range_cnt,
                              const uint32_t* keep, const uint32_t* newidx, const float* lmin, const float* lmax, const float* nbox,
-                             uint32_t nn, uint32_t leaf_max, int wide, int quant, int collapse, float4* nodes, const uint32_t* cbase, const uint32_t* tbase,
+                             uint32_t nn, const uint32_t* live, const uint32_t* dk, int wide, int quant, int collapse, float4* nodes, const uint32_t* cbase, const uint32_t* tbase,
                              const float4* tris_morton, float4* tris_out) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nn; i += gridDim.x * blockDim.x) {
         if (!keep[i]) continue;
         uint32_t sl4[4];
-        const uint32_t ns4 = gather_slots(i, left, right, range_cnt, nbox, leaf_max, wide, collapse, sl4);
+        const uint32_t ns4 = gather_slots(i, left, right, live, nbox, dk, wide, collapse, sl4);
         const uint32_t s0 = sl4[0], s1 = sl4[1], s2 = sl4[2], s3 = sl4[3];
         const bool v2 = ns4 > 2, v3 = ns4 > 3;
         const uint32_t o = newidx[i];
@@ -545,7 +687,7 @@ __global__ void k_emit_nodes(const uint32_t* left, const uint32_t* right, const 
             const uint32_t ns = 2u + (v2 ? 1u : 0u) + (v3 ? 1u : 0u);
             float qmn[4][3], qmx[4][3];
             uint32_t qref[4] = {0, 0, 0, 0};
-            for (uint32_t k = 0; k < ns; k++) slot_of(sl[k], lmin, lmax, nbox, range_lo, range_cnt, newidx, leaf_max, qmn[k], qmx[k], qref[k]);
+            for (uint32_t k = 0; k < ns; k++) slot_of(sl[k], lmin, lmax, nbox, range_lo, range_cnt, newidx, live, qmn[k], qmx[k], qref[k]);
             if (quant == 2) {
                 uint32_t meta[4] = {7u, 7u, 7u, 7u}, tcur = tbase[i];
                 for (uint32_t k = 0; k < ns; k++) {
@@ -569,7 +711,7 @@ __global__ void k_emit_nodes(const uint32_t* left, const uint32_t* right, const 
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (vl[k]) {
-                    slot_of(sl[k], lmin, lmax, nbox, range_lo, range_cnt, newidx, leaf_max, mn, mx, ref);
+                    slot_of(sl[k], lmin, lmax, nbox, range_lo, range_cnt, newidx, live, mn, mx, ref);
                 } else {
                     mn[0] = mn[1] = mn[2] = inf;
                     mx[0] = mx[1] = mx[2] = -inf;
@@ -581,8 +723,8 @@ __global__ void k_emit_nodes(const uint32_t* left, const uint32_t* right, const 
         } else {
             float mn1[3], mx1[3];
             uint32_t ref1;
-            slot_of(s0, lmin, lmax, nbox, range_lo, range_cnt, newidx, leaf_max, mn, mx, ref);
-            slot_of(s1, lmin, lmax, nbox, range_lo, range_cnt, newidx, leaf_max, mn1, mx1, ref1);
+            slot_of(s0, lmin, lmax, nbox, range_lo, range_cnt, newidx, live, mn, mx, ref);
+            slot_of(s1, lmin, lmax, nbox, range_lo, range_cnt, newidx, live, mn1, mx1, ref1);
             nodes[4 * (size_t)o + 0] = make_float4(mn[0], mn[1], mn[2], mx[0]);
             nodes[4 * (size_t)o + 1] = make_float4(mx[1], mx[2], mn1[0], mn1[1]);
             nodes[4 * (size_t)o + 2] = make_float4(mn1[2], mx1[0], mx1[1], mx1[2]);
@@ -1859,12 +2001,16 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
     hipError_t err = hipSuccess;
     *out = LbvhResult{};
     out->n_tris = n;
-    const int wide = node_width == 4, quant = wide ? (node_quant > 2 ? 2 : (int)node_quant) : 0, collapse = wide && collapse_mode ? 1 : 0;
+    const int wide = node_width == 4, quant = wide ? (node_quant > 2 ? 2 : (int)node_quant) : 0, collapse = wide ? (collapse_mode > 2 ? 2 : (int)collapse_mode) : 0;
+    const bool dp = collapse == 2;  // cost-driven collapse: tree order + bottom-up dynamic programme; the SAH top then runs on the device whatever sah_device says
     out->node_bytes = (wide && !quant) ? 128u : (quant == 2 ? 16u * kC48Stride : 64u);
     out->layout = !wide ? kLayoutBinary64 : (quant == 2 ? kLayoutWide48Q : (quant ? kLayoutWide64Q : kLayoutWide128));
     if (n == 0) return hipSuccess;
     const uint32_t nn = n > 1 ? n - 1 : 1;
     float *bmin = nullptr, *bmax = nullptr, *lmin = nullptr, *lmax = nullptr, *nbox = nullptr;
+    uint32_t *live = nullptr, *dk = nullptr, *newpos = nullptr;
+    float *dc = nullptr, *lmin2 = nullptr, *lmax2 = nullptr;
+    float4* tris_dp = nullptr;  // cost-driven collapse: Morton-ordered triangle records before they move into tree order
     uint32_t *bounds = nullptr, *vals_in = nullptr, *vals_out = nullptr, *left = nullptr, *right = nullptr, *pint = nullptr, *pleaf = nullptr,
              *arrive = nullptr, *levels = nullptr, *rlo = nullptr, *rcnt = nullptr, *keep = nullptr, *newidx = nullptr, *n_int = nullptr,
              *n_ltri = nullptr, *cbase = nullptr, *tbase = nullptr;
@@ -1889,7 +2035,7 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
         size_t sort_bytes = 0, scan_bytes = 0;
         LB_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, 63, st));
         LB_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, keep, newidx, (int)nn, st));
-        LB_CHECK(arena.reserve((size_t)n * 320 + sort_bytes + 2 * scan_bytes + ((size_t)1 << 20)));
+        LB_CHECK(arena.reserve((size_t)n * 448 + sort_bytes + 2 * scan_bytes + ((size_t)1 << 20)));
     }
     LB_CHECK(arena.take(&bmin, (size_t)n * 12));
     LB_CHECK(arena.take(&bmax, (size_t)n * 12));
@@ -1911,6 +2057,15 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
     LB_CHECK(arena.take(&keep, (size_t)nn * 4));
     LB_CHECK(arena.take(&newidx, (size_t)nn * 4));
     LB_CHECK(arena.take(&levels, 4));
+    LB_CHECK(arena.take(&live, (size_t)nn * 4));
+    if (dp && n > 1) {
+        LB_CHECK(arena.take(&dk, (size_t)nn * 4));
+        LB_CHECK(arena.take(&dc, (size_t)nn * 12));
+        LB_CHECK(arena.take(&newpos, (size_t)n * 4));
+        LB_CHECK(arena.take(&lmin2, (size_t)n * 12));
+        LB_CHECK(arena.take(&lmax2, (size_t)n * 12));
+        LB_CHECK(arena.take(&tris_dp, (size_t)n * 48));
+    }
     LB_CHECK(hipMalloc(&out->tris, (size_t)n * 48 + 128));  // + slack: the traversal fetch may over-read the last leaf by up to 128 B
     LB_CHECK(hipMemsetAsync((char*)out->tris + (size_t)n * 48, 0, 128, st));
     LB_CHECK(hipMalloc(&out->tri_shade, (size_t)n * 16));
@@ -1932,7 +2087,7 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
     LB_CHECK(arena.take(&temp, temp_bytes ? temp_bytes : 16));
     LB_CHECK(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (int)n, 0, 63, st));
     hipLaunchKernelGGL(k_leaves, dim3(grid), dim3(256), 0, st, verts, indices, geoms, prim_geom, first_prim, vals_out, bmin, bmax, bounds, n,
-                       tris_morton ? tris_morton : out->tris, lmin, lmax);
+                       tris_dp ? tris_dp : (tris_morton ? tris_morton : out->tris), lmin, lmax);
     if (n == 1) {
         LB_CHECK(hipMalloc(&out->nodes, out->node_bytes));
         hipLaunchKernelGGL(k_single, dim3(1), dim3(1), 0, st, lmin, lmax, wide, quant, out->nodes);
@@ -1942,7 +2097,10 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
         LB_CHECK(hipStreamSynchronize(st));
     } else {
         hipLaunchKernelGGL(k_hierarchy, dim3(grid), dim3(256), 0, st, keys_out, (int)n, left, right, pint, pleaf, rlo, rcnt);
-        const uint32_t T_sah = sah_top > leaf_max ? sah_top : leaf_max;
+        // clusters of the SAH top: Karras subtrees of at most T triangles.  Without tree order a multi-triangle leaf must be a Morton range,
+        // so T >= leaf_max; with it (cost-driven collapse) T goes down to single triangles
+        const uint32_t T_sah = dp ? sah_top : (sah_top > leaf_max ? sah_top : leaf_max);
+        if (dp) sah_device = 1;
         const bool lite = sah_top && sah_device && T_sah <= 64;  // the SAH top only reads the cluster boxes and writes every box above them itself
         if (lite) hipLaunchKernelGGL(k_refit_clusters, dim3(grid), dim3(256), 0, st, rlo, rcnt, lmin, lmax, nn, T_sah, nbox);
         else hipLaunchKernelGGL(k_refit, dim3(grid), dim3(256), 0, st, left, right, pint, pleaf, lmin, lmax, n, nbox, arrive);
@@ -2005,6 +2163,19 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
             }
         }
         const auto t3 = std::chrono::steady_clock::now();
+        if (dp) {
+            // bottom-up: true triangle counts, the collapse costs and choices; then every triangle's / node's place in tree order, and the move
+            LB_CHECK(hipMemsetAsync(arrive, 0, (size_t)nn * 4, st));
+            hipLaunchKernelGGL(k_dp_up, dim3(grid), dim3(256), 0, st, left, right, pint, pleaf, lmin, lmax, nbox, n, leaf_max, rcnt, dc, dk, live, arrive);
+            const unsigned g3 = (unsigned)(((uint64_t)n + nn + 255) / 256 > 4096 ? 4096 : ((uint64_t)n + nn + 255) / 256);
+            hipLaunchKernelGGL(k_tree_order, dim3(g3), dim3(256), 0, st, left, right, pint, pleaf, rcnt, n, nn, newpos, rlo);
+            float4* tris_to = quant == 2 ? tris_morton : out->tris;  // (the compact layout moves them once more, into leaf order, when it emits)
+            hipLaunchKernelGGL(k_tree_reorder, dim3(g3), dim3(256), 0, st, newpos, n, nn, tris_dp, tris_to, lmin, lmax, lmin2, lmax2, left, right);
+            lmin = lmin2;
+            lmax = lmax2;
+        } else {
+            hipLaunchKernelGGL(k_live_flags, dim3(grid), dim3(256), 0, st, rcnt, nn, leaf_max, live);
+        }
         if (collapse) {
             // top-down, one four-wide level per launch (the frontier of level l+1 is produced by level l); ~log4(n) launches, sixteen at a
             // time between looks at the frontier counters (fr_n[l] = size of level l's frontier)
@@ -2022,7 +2193,7 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
             uint32_t level = 0, last = 1;
             while (e2 == hipSuccess && last > 0 && level + 16 < n_cnt) {
                 for (int burst = 0; burst < 16; burst++, level++) {
-                    hipLaunchKernelGGL(k_wide_level, dim3(g2), dim3(256), 0, st, left, right, rcnt, nbox, leaf_max, fr_a, fr_n + level, keep, fr_b, fr_n + level + 1);
+                    hipLaunchKernelGGL(k_wide_level, dim3(g2), dim3(256), 0, st, left, right, live, nbox, dk, collapse, fr_a, fr_n + level, keep, fr_b, fr_n + level + 1);
                     std::swap(fr_a, fr_b);
                 }
                 e2 = hipMemcpyAsync(&last, fr_n + level, 4, hipMemcpyDeviceToHost, st);
@@ -2039,7 +2210,7 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
             LB_CHECK(hipMemcpyAsync(levels, &lv, 4, hipMemcpyHostToDevice, st));
             LB_CHECK(hipStreamSynchronize(st));
         } else {
-            hipLaunchKernelGGL(k_keep_flags, dim3(grid), dim3(256), 0, st, pint, rcnt, nn, leaf_max, wide, keep, levels);
+            hipLaunchKernelGGL(k_keep_flags, dim3(grid), dim3(256), 0, st, pint, live, nn, wide, keep, levels);
         }
         LB_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, temp2_bytes, keep, newidx, (int)nn, st));
         LB_CHECK(arena.take(&temp2, temp2_bytes ? temp2_bytes : 16));
@@ -2051,12 +2222,12 @@ hipError_t lbvh_build(hipStream_t st, const float* verts, const uint32_t* indice
         out->n_nodes = tail[0] + tail[1];
         LB_CHECK(hipMalloc(&out->nodes, (size_t)out->n_nodes * out->node_bytes));
         if (quant == 2) {
-            hipLaunchKernelGGL(k_child_counts, dim3(grid), dim3(256), 0, st, left, right, rcnt, nbox, keep, nn, leaf_max, collapse, n_int, n_ltri);
+            hipLaunchKernelGGL(k_child_counts, dim3(grid), dim3(256), 0, st, left, right, rcnt, nbox, keep, nn, live, dk, collapse, n_int, n_ltri);
             LB_CHECK(hipcub::DeviceScan::ExclusiveSum(temp2, temp2_bytes, n_int, cbase, (int)nn, st));
             LB_CHECK(hipcub::DeviceScan::ExclusiveSum(temp2, temp2_bytes, n_ltri, tbase, (int)nn, st));
-            hipLaunchKernelGGL(k_assign_index, dim3(grid), dim3(256), 0, st, left, right, rcnt, nbox, keep, nn, leaf_max, collapse, cbase, newidx);
+            hipLaunchKernelGGL(k_assign_index, dim3(grid), dim3(256), 0, st, left, right, live, nbox, keep, nn, dk, collapse, cbase, newidx);
         }
-        hipLaunchKernelGGL(k_emit_nodes, dim3(grid), dim3(256), 0, st, left, right, rlo, rcnt, keep, newidx, lmin, lmax, nbox, nn, leaf_max, wide,
+        hipLaunchKernelGGL(k_emit_nodes, dim3(grid), dim3(256), 0, st, left, right, rlo, rcnt, keep, newidx, lmin, lmax, nbox, nn, live, dk, wide,
                            quant, collapse, out->nodes, cbase, tbase, tris_morton, out->tris);
         if (wide && quant == 1) {  // top-of-tree copy the traversal kernels keep in LDS
             uint32_t* d_ntop = nullptr;

@@ -105,7 +105,7 @@ INSTANCE_DTYPE = np.dtype([("geometry_first", np.uint32), ("geometry_count", np.
 
 
 class Scene:
-    def __init__(self, mesh, sky=None, bluenoise=None, build=True, leaf_size=2, node_width=4, quantized=1, collapse=1, sah_top=2, tree_order=0, instances=None):
+    def __init__(self, mesh, sky=None, bluenoise=None, build=True, leaf_size=2, node_width=4, quantized=1, collapse=2, sah_top=1, tree_order=0, instances=None):
         L = lib()
         self.h = L.orc_scene_create()
         L.orc_accel_set_layout(self.h, leaf_size, node_width, quantized)
