@@ -418,6 +418,7 @@ struct orc_scene {
     uint32_t n_flat; uint32_t *flat_geom, *flat_inst; uint8_t *flat_identity;
     /* accel */
     uint32_t n_tris, n_nodes, max_depth, leaf_max, node_width, node_quant, collapse, sah_top, tree_order;
+    float dp_c_node, dp_c_tri; /* experiment knob of the cost-driven collapse (tests/experiments/tree_quality_gpu.py); both 1 = the product's rule */
     float *nodes;   /* 16 words per node */
     float *tris;    /* 12 words per tri (Morton order) */
     uint64_t *codes;
@@ -440,6 +441,7 @@ orc_scene *orc_scene_create(void) {
     s->node_quant = 1;
     s->collapse = 2; /* cost-driven collapse over a binned-SAH tree down to single triangles (round 3) */
     s->sah_top = 1;
+    s->dp_c_node = s->dp_c_tri = 1.0f;
     for (int i = 0; i < 256; i++) { /* sRGB EOTF, IEC 61966-2-1, in double */
         double c = i / 255.0;
         s->srgb_lut[i] = (float)(c <= 0.04045 ? c / 12.92 : pow((c + 0.055) / 1.055, 2.4));
@@ -454,6 +456,7 @@ void orc_accel_set_layout(orc_scene *s, uint32_t leaf_max, uint32_t node_width, 
 }
 void orc_accel_set_collapse(orc_scene *s, uint32_t mode) { s->collapse = mode > 2u ? 2u : mode; }
 void orc_accel_set_tree_order(orc_scene *s, uint32_t on) { s->tree_order = on ? 1u : 0u; }
+void orc_accel_set_dp_costs(orc_scene *s, float c_node, float c_tri) { s->dp_c_node = c_node; s->dp_c_tri = c_tri; }
 void orc_accel_set_sah_top(orc_scene *s, uint32_t cluster_size) { s->sah_top = cluster_size; }
 uint32_t orc_accel_node_words(const orc_scene *s) { return s->node_width == 2 ? 16u : (s->node_quant == 2 ? 12u : (s->node_quant ? 16u : 32u)); }
 
@@ -1091,15 +1094,16 @@ int orc_accel_build(orc_scene *s) {
             for (uint32_t q = n_order; q-- > 0;) {
                 uint32_t i = order[q], l = left[i], r = right[i];
                 float Cl[3], Cr[3];
-                if (l & 0x80000000u) { float a = half_area3(lmin + 3 * (l & 0x7FFFFFFFu), lmax + 3 * (l & 0x7FFFFFFFu)); Cl[0] = Cl[1] = Cl[2] = a; }
+                if (l & 0x80000000u) { float a = half_area3(lmin + 3 * (l & 0x7FFFFFFFu), lmax + 3 * (l & 0x7FFFFFFFu)); if (s->dp_c_tri != 1.0f) a = a * s->dp_c_tri; Cl[0] = Cl[1] = Cl[2] = a; }
                 else { Cl[0] = dc[3 * l]; Cl[1] = dc[3 * l + 1]; Cl[2] = dc[3 * l + 2]; }
-                if (r & 0x80000000u) { float a = half_area3(lmin + 3 * (r & 0x7FFFFFFFu), lmax + 3 * (r & 0x7FFFFFFFu)); Cr[0] = Cr[1] = Cr[2] = a; }
+                if (r & 0x80000000u) { float a = half_area3(lmin + 3 * (r & 0x7FFFFFFFu), lmax + 3 * (r & 0x7FFFFFFFu)); if (s->dp_c_tri != 1.0f) a = a * s->dp_c_tri; Cr[0] = Cr[1] = Cr[2] = a; }
                 else { Cr[0] = dc[3 * r]; Cr[1] = dc[3 * r + 1]; Cr[2] = dc[3 * r + 2]; }
                 float d2 = Cl[0] + Cr[0];
                 float d3 = Cl[0] + Cr[1]; uint32_t k3 = 1; { float b = Cl[1] + Cr[0]; if (b < d3) { d3 = b; k3 = 2; } }
                 float d4 = Cl[0] + Cr[2]; uint32_t k4 = 1; { float b = Cl[1] + Cr[1]; if (b < d4) { d4 = b; k4 = 2; } b = Cl[2] + Cr[0]; if (b < d4) { d4 = b; k4 = 3; } }
                 float A = half_area3(nmin + 3 * i, nmax + 3 * i);
                 float cint = A + d4, cleaf = (float)rcnt[i] * A;
+                if (s->dp_c_node != 1.0f || s->dp_c_tri != 1.0f) { cint = A * s->dp_c_node + d4; cleaf = ((float)rcnt[i] * A) * s->dp_c_tri; }
                 uint32_t leaf1 = i != 0 && rcnt[i] <= K && cleaf <= cint;
                 float c1 = leaf1 ? cleaf : cint;
                 uint32_t s2 = d2 < c1; float c2 = s2 ? d2 : c1;

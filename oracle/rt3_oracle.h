@@ -122,6 +122,8 @@ void orc_accel_set_collapse(orc_scene *s, uint32_t mode);
 /* tree order: triangle records re-ordered depth-first along the final binary tree, so that every subtree is a contiguous range
  * (lets the SAH top go down to single triangles, cluster_size 1, with multi-triangle leaves formed above them) */
 void orc_accel_set_tree_order(orc_scene *s, uint32_t on);
+/* experiments only: weights of a node step / a triangle step in the cost-driven collapse (the product uses 1, 1) */
+void orc_accel_set_dp_costs(orc_scene *s, float c_node, float c_tri);
 /* SAH top: the tree above Karras subtrees of at most cluster_size triangles is re-linked by binned SAH (0 = plain LBVH; default 2) */
 void orc_accel_set_sah_top(orc_scene *s, uint32_t cluster_size);
 uint32_t orc_accel_node_words(const orc_scene *s);

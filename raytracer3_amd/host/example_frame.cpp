@@ -52,7 +52,6 @@ int main(int argc, char** argv) {
         rt3::Context ctx(n_ranks ? (getenv("RT3_DEVICE") ? atoi(getenv("RT3_DEVICE")) : (int)rank) : 0);
         ctx.check(rt3_set_tile_partition(ctx.raw(), W, H, rank, n_ranks ? n_ranks : 1u), "partition");
         if (n_ranks) {  // rank 0's id travels over whatever channel the host has -- here a file
-            if (probes) throw std::runtime_error("the probe-GI passes are not tile-partitioned");
             const char* uid_file = getenv("RT3_UID_FILE");
             if (!uid_file) throw std::runtime_error("RT3_UID_FILE is not set");
             unsigned char id[RT3_COMM_ID_BYTES];
@@ -129,7 +128,15 @@ int main(int argc, char** argv) {
                            .write(rt3::IMPORTED, sh).read(tp, atlas).dispatch(rt3::DispatchSize::XY(px, py));
             rt3::ComputePass::New(rg, "interpolate_probes").shader("interpolate_probes").constants(gconst)
                 .read(gb, gbuffer).read(gb, depth).read(shc, sh).write(rt3::IMPORTED, light).dispatch(rt3::DispatchSize::FullScreen());
+            // under a tile partition the probe chain runs replicated: every rank renders it for the whole window (it reads the whole G-buffer and
+            // is launch-bound well under a millisecond), then the frame-end gather of each rank's own tiles assembles the root's image
+            if (n_ranks > 1) ctx.check(rt3_set_tile_partition(ctx.raw(), W, H, 0, 1), "partition off");
             rg.draw_frame(light);
+            if (n_ranks > 1) {
+                ctx.check(rt3_set_tile_partition(ctx.raw(), W, H, rank, n_ranks), "partition on");
+                ctx.check(rt3_gather_tiles(ctx.raw(), light, 0), "gather");
+                if (rank != 0) return 0;
+            }
             std::vector<float> out((size_t)W * H * 4), at((size_t)px * 8 * py * 8 * 4);
             ctx.check(rt3_resource_download(ctx.raw(), light, out.data(), out.size() * 4), "download");
             ctx.check(rt3_resource_download(ctx.raw(), atlas, at.data(), at.size() * 4), "download");

@@ -96,10 +96,11 @@ class PathTracer:
         return self.handles
 
     def probe_commands(self, gconst: L.GConst):
-        """The probe-GI frame: one probe per 16x16 pixel block, 8x8 rays per probe in the probe atlas.  Single rank only (the
-        probe passes read the whole G-buffer).  Returns the handles; `Light` receives the interpolated image."""
-        if self.n_ranks != 1:
-            raise ValueError("the probe-GI passes are not tile-partitioned: run them with n_ranks == 1")
+        """The probe-GI frame: one probe per 16x16 pixel block, 8x8 rays per probe in the probe atlas.  Returns the handles; `Light`
+        receives the interpolated image.  Under a tile partition (n_ranks > 1) the chain runs REPLICATED: it reads the whole G-buffer
+        (jittered neighbours, probes up to two cells away, red marks scattered to other pixels) and is launch-bound at well under a
+        millisecond, so every rank renders it for the full window (render_probes switches the partition off around it) and the
+        frame-end gather of each rank's own tiles assembles the same image on the root as a single rank would produce."""
         rg = self.rg
         rg.begin_frame()
         W, H = self.window
@@ -130,7 +131,14 @@ class PathTracer:
 
     def render_probes(self, gconst, wait=True):
         h = self.probe_commands(gconst)
-        self.rg.draw_frame(h["light"], wait=wait)
+        W, H = self.window
+        if self.n_ranks > 1:  # replicas: the whole window on every rank (see probe_commands)
+            self.ctx.set_tile_partition(W, H, 0, 1)
+        try:
+            self.rg.draw_frame(h["light"], wait=wait)
+        finally:
+            if self.n_ranks > 1:  # launches read the partition when they are enqueued: safe to restore behind them
+                self.ctx.set_tile_partition(W, H, self.rank, self.n_ranks)
         return h
 
     def copy_atlas_to_prev(self):

@@ -41,16 +41,32 @@ while time.time() < t_end:
     n_ranks = int(rng.choice([1, 1, 2, 3, 5, 8]))
     rank = int(rng.integers(n_ranks))
     batch = int(rng.choice([0, 0, 1, 2]))
-    leaf, T = int(rng.choice([1, 2, 2, 3, 4])), int(rng.choice([0, 2, 2, 4, 16]))
+    leaf, T = int(rng.choice([1, 2, 2, 3, 4])), int(rng.choice([0, 1, 1, 2, 4, 16]))
+    collapse = int(rng.choice([2, 2, 2, 1, 0]))  # cost-driven (default), surface area, even depth
+    # instances (round 3): the whole scene once under the identity plus, sometimes, one or two of its geometries placed again under random
+    # rigid / scaled matrices inside the scene's box
+    inst = []
+    if rng.random() < 0.35:
+        ng = len(mesh.geometries)
+        inst.append((0, ng, np.eye(4, dtype=np.float32)))
+        for _ in range(int(rng.integers(1, 3))):
+            gsel = int(rng.integers(ng))
+            a, sc, tr = float(rng.uniform(-3.1, 3.1)), rng.uniform(0.3, 1.5, 3), rng.uniform(lo, hi) * 0.3
+            m = np.array([[math.cos(a) * sc[0], 0, math.sin(a) * sc[2], tr[0]], [0, sc[1], 0, tr[1]], [-math.sin(a) * sc[0], 0, math.cos(a) * sc[2], tr[2]], [0, 0, 0, 1]], np.float32)
+            inst.append((gsel, 1, m))
     pos = rng.uniform(lo, hi)
     d = rng.normal(size=3)
     d /= np.linalg.norm(d)
     fov = float(rng.uniform(20, 100))
     params = dict(scene=name, sky=None if sky is None else sky.shape[:2], size=(W, H), spp=spp, bounces=bounces, flags=flags, frame=frame, rank=(rank, n_ranks), batch=batch,
-                  leaf=leaf, T=T, pos=[round(float(x), 4) for x in pos], dir=[round(float(x), 4) for x in d], fov=round(fov, 2))
+                  leaf=leaf, T=T, collapse=collapse, instances=len(inst), pos=[round(float(x), 4) for x in pos], dir=[round(float(x), 4) for x in d], fov=round(fov, 2))
     pt = PathTracer((W, H), rank=rank, n_ranks=n_ranks)
     pt.ctx.set_option(L.OPT_LEAF_SIZE, leaf)
     pt.ctx.set_option(L.OPT_SAH_TOP, T)
+    pt.ctx.set_option(L.OPT_WIDE_COLLAPSE, collapse)
+    if inst:
+        pt.ctx.upload_mesh(mesh)
+        pt.ctx.set_instances(inst)
     pt.set_scene(mesh, sky, bn)
     if batch:
         pt.ctx.set_option(L.OPT_BATCH_SPP, batch)
@@ -61,7 +77,7 @@ while time.time() < t_end:
     _, depth = pt.gbuffer()
     st = pt.ctx.stats()
     pt.close()
-    osc = orc.Scene(mesh, sky, bn, leaf_size=leaf, sah_top=T)
+    osc = orc.Scene(mesh, sky, bn, leaf_size=leaf, sah_top=T, collapse=collapse, instances=inst or None)
     og = as_orc(g)
     ogb, odepth = osc.gbuffer(og)
     olight, counts = osc.reference_mode(og, ogb, odepth)

@@ -36,8 +36,11 @@ def run(tag):
     return pt.light().copy()
 
 ref = run('device build (default)')
-variants = [('oracle default (same tree)', dict()), ('T=2 DP collapse', dict(sah_top=2, collapse=2)), ('T=1 DP collapse', dict(sah_top=1, collapse=2)),
-            ('T=1 DP leaf<=3', dict(sah_top=1, collapse=2, leaf_size=3)), ('T=1 area, tree order', dict(sah_top=1, collapse=1, tree_order=1))]
+variants = [('oracle default (same tree)', dict()), ('round 2: T=2, area collapse', dict(sah_top=2, collapse=1)), ('T=2 DP collapse', dict(sah_top=2, collapse=2)),
+            ('T=1 DP leaf<=3', dict(sah_top=1, collapse=2, leaf_size=3)), ('T=1 DP leaf<=4', dict(sah_top=1, collapse=2, leaf_size=4)),
+            ('T=1 area, tree order', dict(sah_top=1, collapse=1, tree_order=1)),
+            ('DP c_node 1 c_tri 0.5', dict(dp_costs=(1.0, 0.5))), ('DP c_node 1 c_tri 1.5', dict(dp_costs=(1.0, 1.5))), ('DP c_node 1 c_tri 2', dict(dp_costs=(1.0, 2.0))),
+            ('DP c_node 2 c_tri 1', dict(dp_costs=(2.0, 1.0))), ('DP c_node 0.5 c_tri 1, leaf<=4', dict(dp_costs=(0.5, 1.0), leaf_size=4))]
 for name, kw in variants:
     osc = orc.Scene(mesh, **kw)
     pt.ctx.accel_import(osc.nodes(), osc.tris())
