@@ -15,6 +15,7 @@
 #include "rt3_oracle.h"
 #include <math.h>
 #include <pthread.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -418,6 +419,7 @@ struct orc_scene {
     uint32_t n_flat; uint32_t *flat_geom, *flat_inst; uint8_t *flat_identity;
     /* accel */
     uint32_t n_tris, n_nodes, max_depth, leaf_max, node_width, node_quant, collapse, sah_top, tree_order;
+    uint32_t top_opt, top_opt_passes; /* experiment: insertion-based re-optimisation of the tree above subtrees of <= top_opt triangles */
     float dp_c_node, dp_c_tri; /* experiment knob of the cost-driven collapse (tests/experiments/tree_quality_gpu.py); both 1 = the product's rule */
     float *nodes;   /* 16 words per node */
     float *tris;    /* 12 words per tri (Morton order) */
@@ -457,6 +459,7 @@ void orc_accel_set_layout(orc_scene *s, uint32_t leaf_max, uint32_t node_width, 
 void orc_accel_set_collapse(orc_scene *s, uint32_t mode) { s->collapse = mode > 2u ? 2u : mode; }
 void orc_accel_set_tree_order(orc_scene *s, uint32_t on) { s->tree_order = on ? 1u : 0u; }
 void orc_accel_set_dp_costs(orc_scene *s, float c_node, float c_tri) { s->dp_c_node = c_node; s->dp_c_tri = c_tri; }
+void orc_accel_set_top_opt(orc_scene *s, uint32_t k_top, uint32_t passes) { s->top_opt = k_top; s->top_opt_passes = passes; }
 void orc_accel_set_sah_top(orc_scene *s, uint32_t cluster_size) { s->sah_top = cluster_size; }
 uint32_t orc_accel_node_words(const orc_scene *s) { return s->node_width == 2 ? 16u : (s->node_quant == 2 ? 12u : (s->node_quant ? 16u : 32u)); }
 
@@ -874,6 +877,97 @@ static void sah_top_rebuild(uint32_t nn, uint32_t *left, uint32_t *right, uint32
     }
     free(cl); free(pool); free(idx); free(tmp); free(st);
 }
+/* ---- [experiment, round 3] insertion-based optimisation of the TOP of the tree (after Bittner, Hapala, Havran 2013).  The treelet =
+ * the internal nodes covering more than k_top triangles; its leaves = their children that do not (fixed subtrees).  Every treelet
+ * element in turn is taken out (its parent goes with it, the sibling moves up) and put back where the summed half area of the treelet's
+ * internal nodes grows least (exhaustive search with pruning; the old place is among the candidates, so the sum never grows).
+ * Sequential and deterministic.  Node ids are reused (the freed parent becomes the new parent). */
+typedef struct { uint32_t *left, *right, *par, *parleaf, *cnt; float *nmin, *nmax; const float *lmin, *lmax; uint32_t ktop; } topt;
+static inline const float *tbox_mn(const topt *t, uint32_t r) { return (r & 0x80000000u) ? t->lmin + 3 * (size_t)(r & 0x7FFFFFFFu) : t->nmin + 3 * (size_t)r; }
+static inline const float *tbox_mx(const topt *t, uint32_t r) { return (r & 0x80000000u) ? t->lmax + 3 * (size_t)(r & 0x7FFFFFFFu) : t->nmax + 3 * (size_t)r; }
+static inline uint32_t tcount(const topt *t, uint32_t r) { return (r & 0x80000000u) ? 1u : t->cnt[r]; }
+static inline int t_internal(const topt *t, uint32_t r) { return !(r & 0x80000000u) && t->cnt[r] > t->ktop; }
+static inline void tset_parent(topt *t, uint32_t r, uint32_t p) { if (r & 0x80000000u) t->parleaf[r & 0x7FFFFFFFu] = p; else t->par[r] = p; }
+static inline uint32_t tget_parent(const topt *t, uint32_t r) { return (r & 0x80000000u) ? t->parleaf[r & 0x7FFFFFFFu] : t->par[r]; }
+static void trefit_up(topt *t, uint32_t i) {
+    while (i != 0xFFFFFFFFu) {
+        uint32_t l = t->left[i], r = t->right[i];
+        for (int j = 0; j < 3; j++) { t->nmin[3 * (size_t)i + j] = fminx(tbox_mn(t, l)[j], tbox_mn(t, r)[j]); t->nmax[3 * (size_t)i + j] = fmaxx(tbox_mx(t, l)[j], tbox_mx(t, r)[j]); }
+        t->cnt[i] = tcount(t, l) + tcount(t, r);
+        i = t->par[i];
+    }
+}
+static inline float union_area(const float *amn, const float *amx, const float *bmn, const float *bmx) {
+    float mn[3], mx[3];
+    for (int j = 0; j < 3; j++) { mn[j] = fminx(amn[j], bmn[j]); mx[j] = fmaxx(amx[j], bmx[j]); }
+    return half_area3(mn, mx);
+}
+static void top_optimize(uint32_t nn, uint32_t n_leaves, uint32_t *left, uint32_t *right, uint32_t *rcnt, float *nmin, float *nmax, const float *lmin,
+                         const float *lmax, uint32_t ktop, uint32_t passes) {
+    topt t = {left, right, (uint32_t *)malloc((size_t)nn * 4), (uint32_t *)malloc((size_t)n_leaves * 4), rcnt, nmin, nmax, lmin, lmax, ktop};
+    /* true counts + parents (pre-order list, then reversed) */
+    uint32_t *order = (uint32_t *)malloc((size_t)nn * 4), no = 0, *stk = (uint32_t *)malloc((size_t)nn * 8 + 64);
+    { int sp = 0; stk[sp++] = 0; t.par[0] = 0xFFFFFFFFu;
+      while (sp > 0) { uint32_t i = stk[--sp]; order[no++] = i; uint32_t c2[2] = {left[i], right[i]};
+          for (int c = 0; c < 2; c++) { tset_parent(&t, c2[c], i); if (!(c2[c] & 0x80000000u)) stk[sp++] = c2[c]; } } }
+    for (uint32_t q = no; q-- > 0;) { uint32_t i = order[q]; rcnt[i] = tcount(&t, left[i]) + tcount(&t, right[i]); }
+    /* the elements to move: every child of a treelet-internal node except the root's own children; largest parent box first would be Bittner's
+     * priority -- a fixed pre-order sweep per pass is enough for a prototype */
+    uint32_t *elems = (uint32_t *)malloc((size_t)nn * 8 + 64), ne;
+    double before = 0.0, after = 0.0;
+    for (uint32_t q = 0; q < no; q++) if (t_internal(&t, order[q])) before += half_area3(nmin + 3 * (size_t)order[q], nmax + 3 * (size_t)order[q]);
+    for (uint32_t pass = 0; pass < passes; pass++) {
+        ne = 0;
+        { int sp = 0; stk[sp++] = 0;
+          while (sp > 0) { uint32_t i = stk[--sp]; uint32_t c2[2] = {left[i], right[i]};
+              for (int c = 0; c < 2; c++) { if (i != 0) elems[ne++] = c2[c]; if (t_internal(&t, c2[c])) stk[sp++] = c2[c]; } } }
+        for (uint32_t e = 0; e < ne; e++) {
+            const uint32_t nref = elems[e], p = tget_parent(&t, nref);
+            if (p == 0xFFFFFFFFu || p == 0u) continue;            /* (moved under the root meanwhile) */
+            const uint32_t g = t.par[p];
+            if (g == 0xFFFFFFFFu) continue;
+            const uint32_t sib = left[p] == nref ? right[p] : left[p];
+            /* take n (and p) out */
+            if (left[g] == p) left[g] = sib; else right[g] = sib;
+            tset_parent(&t, sib, g);
+            trefit_up(&t, g);
+            if (!t_internal(&t, g) && g != 0) { /* g fell out of the treelet: keep it simple, undo */
+                if (left[g] == sib) left[g] = p; else right[g] = p;
+                tset_parent(&t, sib, p); t.par[p] = g; trefit_up(&t, p); continue;
+            }
+            const float *bmn = tbox_mn(&t, nref), *bmx = tbox_mx(&t, nref);
+            /* best place: DFS over the treelet with the induced cost of the ancestors carried along */
+            float best = INFINITY; uint32_t best_x = sib;
+            typedef struct { uint32_t ref; float induced; } cand;
+            cand *cs = (cand *)stk; int sp = 0;
+            cs[sp++] = (cand){0u, 0.0f};
+            const float an = half_area3(bmn, bmx);
+            while (sp > 0) {
+                cand c = cs[--sp];
+                if (c.induced + an >= best) continue;
+                const float *xmn = tbox_mn(&t, c.ref), *xmx = tbox_mx(&t, c.ref);
+                const float ua = union_area(xmn, xmx, bmn, bmx);
+                if (c.ref != 0u) { float cost = c.induced + ua; if (cost < best) { best = cost; best_x = c.ref; } }
+                if (t_internal(&t, c.ref)) {
+                    float ind = c.induced + (ua - half_area3(xmn, xmx));
+                    cs[sp++] = (cand){right[c.ref], ind};
+                    cs[sp++] = (cand){left[c.ref], ind};
+                }
+            }
+            /* put it back: p becomes the parent of {best_x, n} in best_x's place */
+            const uint32_t px = tget_parent(&t, best_x);
+            if (left[px] == best_x) left[px] = p; else right[px] = p;
+            t.par[p] = px; left[p] = best_x; right[p] = nref;
+            tset_parent(&t, best_x, p); tset_parent(&t, nref, p);
+            trefit_up(&t, p);
+        }
+    }
+    { int sp = 0; stk[sp++] = 0; while (sp > 0) { uint32_t i = stk[--sp]; after += half_area3(nmin + 3 * (size_t)i, nmax + 3 * (size_t)i);
+          if (t_internal(&t, left[i])) stk[sp++] = left[i];
+          if (t_internal(&t, right[i])) stk[sp++] = right[i]; } }
+    if (getenv("ORC_TRACE_BUILD")) fprintf(stderr, "orc top_optimize: k_top %u, %u passes, treelet area sum %.1f -> %.1f\n", ktop, passes, before, after);
+    free(t.par); free(t.parleaf); free(order); free(stk); free(elems);
+}
 /* child slots of four-wide node i under the surface-area collapse (see orc_accel_build); half area = (ex*ey + ey*ez) + ez*ex */
 static uint32_t sah_slots(uint32_t i, const uint32_t *left, const uint32_t *right, const uint32_t *rcnt, const float *nmin, const float *nmax,
                           uint32_t K, uint32_t sl[4]) {
@@ -1018,7 +1112,7 @@ int orc_accel_build(orc_scene *s) {
         uint32_t *stack = (uint32_t *)malloc((size_t)nn * 2 * 4 + 64);
         uint8_t *state = (uint8_t *)calloc(nn, 1);
         uint32_t *depth = (uint32_t *)calloc(nn, 4);
-        for (int pass = 0; pass < 2; pass++) {
+        for (int stage = 0;;) {
         memset(state, 0, nn); memset(depth, 0, (size_t)nn * 4);
         int sp = 0;
         stack[sp++] = 0;
@@ -1036,7 +1130,9 @@ int orc_accel_build(orc_scene *s) {
                 for (int j = 0; j < 3; j++) { nmin[3 * i + j] = fminx(amn[j], bmn[j]); nmax[3 * i + j] = fmaxx(amx[j], bmx[j]); }
             }
         }
-        if (pass == 0) { if (!s->sah_top) break; sah_top_rebuild(nn, left, right, rlo, rcnt, lmin, lmax, nmin, nmax, (s->tree_order || (s->node_width == 4 && s->collapse == 2)) ? s->sah_top : (s->sah_top > s->leaf_max ? s->sah_top : s->leaf_max)); }
+        if (stage == 0) { stage = 1; if (s->sah_top) { sah_top_rebuild(nn, left, right, rlo, rcnt, lmin, lmax, nmin, nmax, (s->tree_order || (s->node_width == 4 && s->collapse == 2)) ? s->sah_top : (s->sah_top > s->leaf_max ? s->sah_top : s->leaf_max)); continue; } }
+        if (stage == 1) { stage = 2; if (s->top_opt && (s->tree_order || (s->node_width == 4 && s->collapse == 2))) { top_optimize(nn, n, left, right, rcnt, nmin, nmax, lmin, lmax, s->top_opt, s->top_opt_passes ? s->top_opt_passes : 2u); continue; } }
+        break;
         }
         /* Multi-triangle leaves: an internal node covering <= leaf_max triangles (contiguous in Morton order) is referenced
          * as a leaf {bit 31, count-1 in bits 30..28, first triangle in bits 27..0}; the root always stays a node.

@@ -27,6 +27,11 @@ def measure(osc, W=480, H=270, spp=2, flags=15):
 if __name__ == '__main__':
     mesh = scenes.atrium(1.0); sky = scenes.sky(512, 256); bn = assets.load_bluenoise()
     variants = [
+        ('default (T=1 DP)', dict()),
+        ('top-opt k=64 p=2', dict(top_opt=(64, 2))),
+        ('top-opt k=256 p=2', dict(top_opt=(256, 2))),
+        ('top-opt k=16 p=3', dict(top_opt=(16, 3))),
+        ('top-opt k=1024 p=3', dict(top_opt=(1024, 3))),
         ('baseline T=2 area', dict(sah_top=2, collapse=1)),
         ('T=2 area tree-order', dict(sah_top=2, collapse=1, tree_order=1)),
         ('T=1 area tree-order', dict(sah_top=1, collapse=1, tree_order=1)),
