@@ -305,6 +305,67 @@ def test_shading_record_normals_device_equals_oracle():
     assert np.array_equal(enc, oenc) and np.array_equal(dec.view(np.uint32), odec.view(np.uint32))
 
 
+def test_accel_import_installs_a_foreign_tree_and_refuses_a_broken_one(small):
+    """rt3_accel_import (the way back of rt3_accel_download): a tree built elsewhere over the same triangles -- here the oracle's, with a
+    different builder setting than the device's own -- is installed and walked: hits and per-ray visit counts are the oracle's for THAT tree,
+    frames stay bit-exact; every reference is validated on the host before a kernel may follow it."""
+    mesh, sky, bn, _ = small
+    other = orc.Scene(mesh, sky, bn, sah_top=4, collapse=1, tree_order=1)  # not the device's default tree
+    ctx = Context(0)
+    ctx.upload_mesh(mesh)
+    lib = ctx.lib
+    n, t = np.ascontiguousarray(other.nodes()), np.ascontiguousarray(other.tris())
+    assert lib.rt3_accel_import(ctx.h, n.ctypes.data, n.nbytes, t.ctypes.data, t.nbytes) == L.E_STATE  # rt3_accel_build first
+    ctx.build_accel()
+    own_nodes, _ = ctx.accel_download()
+    assert not np.array_equal(own_nodes.shape, n.shape) or not np.array_equal(own_nodes, n)
+    ctx.accel_import(n, t)
+    assert ctx.accel_info()[:3] == (other.n_nodes, other.n_tris, other.max_depth)
+    rays = rays_random(30000, 21, [-14, 0.2, -8], [14, 12, 8])
+    tt, u, v, p, cn, ct, _ = ctx.trace_rays(rays, counts=True)
+    ot, ou, ov, op, ocn, oct = other.trace_closest(rays, counts=True)
+    assert np.array_equal(p, op) and np.array_equal(tt[p != L.MISS], ot[p != L.MISS]) and np.array_equal(cn, ocn) and np.array_equal(ct, oct)
+    assert np.array_equal(ctx.trace_rays(rays, any_hit=True)[3] != 0, other.trace_any(rays) != 0)
+    # broken trees: a reference out of range, a node reachable twice (a cycle would never end), a triangle range beyond the array, a foreign primitive id
+    for what, mutate in (("node out of range", lambda a, b: a.__setitem__((0, 10), np.uint32(other.n_nodes + 5))),
+                         ("cycle", lambda a, b: a.__setitem__((1, 10), np.uint32(0))),
+                         ("triangles beyond the array", lambda a, b: a.__setitem__((0, 10), np.uint32(0x80000000 | (1 << 28) | (other.n_tris - 1)))),
+                         ("foreign primitive", lambda a, b: b.__setitem__((3, 9), np.uint32(mesh.n_triangles + 7)))):
+        bad_n, bad_t = n.view(np.uint32).reshape(-1, 16).copy(), t.view(np.uint32).reshape(-1, 12).copy()
+        mutate(bad_n, bad_t)
+        assert lib.rt3_accel_import(ctx.h, bad_n.ctypes.data, bad_n.nbytes, bad_t.ctypes.data, bad_t.nbytes) == L.E_INVALID, what
+    assert lib.rt3_accel_import(ctx.h, n.ctypes.data, n.nbytes - 4, t.ctypes.data, t.nbytes) == L.E_INVALID
+    # the refused imports left the installed tree alone
+    assert np.array_equal(ctx.trace_rays(rays)[3], op)
+    ver = C.c_int(0)
+    assert lib.rt3_comm_version(C.byref(ver)) == 0 and ver.value >= 20000  # the RCCL this library links (NCCL API level)
+    ctx.close()
+
+
+def test_bounce1_batch_of_the_cpu_baseline_is_what_the_gpu_traces(small):
+    """bench.py's CPU baseline walks "the C2 primary batch + the bounce-1 batch" (SURVEY 8d); the bounce-1 batch comes from the oracle
+    (orc_bounce1_rays).  It must be the rays the product traces after the first shade: same number (ray accounting of a 1-spp, 2-bounce
+    frame) and, traced through rt3_trace_rays, the same hits as the oracle's traversal."""
+    mesh, sky, bn, osc = small
+    W, H = 160, 96
+    pt = PathTracer((W, H))
+    pt.set_scene(mesh, sky, bn)
+    cam = Camera(scenes.ATRIUM_CAMERA["position"], scenes.ATRIUM_CAMERA["direction"], math.radians(scenes.ATRIUM_CAMERA["fov_deg"]), W / H)
+    for flags in (0, SPEC):
+        g = pt.make_gconst(cam, 1, 2, frame=5, flags=flags)
+        pt.ctx.stats_reset()
+        pt.render(g)
+        st = pt.ctx.stats()
+        og = as_orc(g)
+        ogb, odepth = osc.gbuffer(og)
+        b1 = osc.bounce1_rays(og, ogb, odepth)
+        assert st.extension_rays - W * H == b1.shape[1] > 0.5 * W * H
+        gt, gu, gv, gp, _ = pt.ctx.trace_rays(b1)
+        ot, ou, ov, op = osc.trace_closest(b1)
+        assert np.array_equal(gp, op) and np.array_equal(gt[gp != L.MISS], ot[op != L.MISS])
+    pt.close()
+
+
 def test_lbvh_edge_cases():
     """empty scene, one triangle, duplicate triangles (identical Morton codes)."""
     ctx = Context(0)
