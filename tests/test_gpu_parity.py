@@ -271,6 +271,13 @@ def test_instances_two_placements_one_moved_between_frames():
     plain = orc.Scene(room, sky, bn)
     nodes, tris = pt.ctx.accel_download()
     assert np.array_equal(nodes, plain.nodes()) and np.array_equal(tris, plain.tris())
+    # an instance list that places nothing is an empty world: every ray misses, on both sides
+    pt.ctx.set_instances([(0, 0, np.eye(4, dtype=np.float32))])
+    pt.ctx.build_accel()
+    rays = rays_random(2000, 3, [-0.9, 0.1, -0.9], [0.9, 1.9, 0.9])
+    assert (pt.ctx.trace_rays(rays)[3] == L.MISS).all() and pt.ctx.accel_info()[1] == 0
+    osc.set_instances([(0, 0, np.eye(4, dtype=np.float32))])
+    assert (osc.trace_closest(rays)[3] == L.MISS).all()
     # bad instances are refused, not dereferenced
     lib = pt.ctx.lib
     bad = (L.Instance * 1)()
