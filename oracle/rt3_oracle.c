@@ -419,6 +419,7 @@ struct orc_scene {
     uint32_t n_flat; uint32_t *flat_geom, *flat_inst; uint8_t *flat_identity;
     /* accel */
     uint32_t n_tris, n_nodes, max_depth, leaf_max, node_width, node_quant, collapse, sah_top, tree_order;
+    uint32_t recull; /* experiment (default 0; the product does not do it: measured slower): re-cull stacked node references on pop */
     uint32_t top_opt, top_opt_passes; /* experiment: insertion-based re-optimisation of the tree above subtrees of <= top_opt triangles */
     float dp_c_node, dp_c_tri; /* experiment knob of the cost-driven collapse (tests/experiments/tree_quality_gpu.py); both 1 = the product's rule */
     float *nodes;   /* 16 words per node */
@@ -459,6 +460,7 @@ void orc_accel_set_layout(orc_scene *s, uint32_t leaf_max, uint32_t node_width, 
 void orc_accel_set_collapse(orc_scene *s, uint32_t mode) { s->collapse = mode > 2u ? 2u : mode; }
 void orc_accel_set_tree_order(orc_scene *s, uint32_t on) { s->tree_order = on ? 1u : 0u; }
 void orc_accel_set_dp_costs(orc_scene *s, float c_node, float c_tri) { s->dp_c_node = c_node; s->dp_c_tri = c_tri; }
+void orc_accel_set_recull(orc_scene *s, uint32_t on) { s->recull = on; }
 void orc_accel_set_top_opt(orc_scene *s, uint32_t k_top, uint32_t passes) { s->top_opt = k_top; s->top_opt_passes = passes; }
 void orc_accel_set_sah_top(orc_scene *s, uint32_t cluster_size) { s->sah_top = cluster_size; }
 uint32_t orc_accel_node_words(const orc_scene *s) { return s->node_width == 2 ? 16u : (s->node_quant == 2 ? 12u : (s->node_quant ? 16u : 32u)); }
@@ -1422,6 +1424,12 @@ static void traverse(const orc_scene *s, const float o[3], const float d[3], flo
         float inv[3] = {guard_inv(d[0]), guard_inv(d[1]), guard_inv(d[2])};
         const float inv_dd = ray_inv_dd(d);
         uint32_t stack[ORC_STACK]; int sp = 0;
+        float sdist[ORC_STACK]; float dsel[4] = {0, 0, 0, 0}; /* experiment (recull): truncated entry distances of the stacked references */
+        /* [round 3 experiment, off by default] re-cull on pop: closest hit, default node layout, trees of at most 2^18 nodes (a kernel would pack
+         * the distance into 12 spare bits of a stacked node reference): a popped NODE reference whose entry distance -- truncated to the float's top 12 bits,
+         * i.e. never above the distance itself -- lies beyond the hit found meanwhile is dropped without a visit; at most ONE reference per pop (the
+         * one below it is then taken as it is), so that the kernel needs no loop */
+        const int recull = s->recull && !any && s->node_width == 4 && s->node_quant == 1 && s->n_nodes <= (1u << 18);
         uint32_t cur = 0;
         const int W4 = s->node_width == 4;
         for (;;) {
@@ -1433,6 +1441,7 @@ static void traverse(const orc_scene *s, const float o[3], const float d[3], flo
                     if (any && best.prim != ORC_MISS) break;
                 }
                 if (any && best.prim != ORC_MISS) break;
+                if (recull && sp > 0 && !(stack[sp - 1] & 0x80000000u) && sdist[sp - 1] > best.t) sp--; /* ONE reference per pop (the kernel's rule) */
                 if (sp == 0) break;
                 cur = stack[--sp];
                 continue;
@@ -1470,7 +1479,7 @@ static void traverse(const orc_scene *s, const float o[3], const float d[3], flo
                         int a = net[c][0], b = net[c][1];
                         if (ct[b] < ct[a]) { float tt = ct[a]; ct[a] = ct[b]; ct[b] = tt; uint32_t rr = cr[a]; cr[a] = cr[b]; cr[b] = rr; }
                     }
-                    for (int k = 0; k < nh; k++) ref[k] = cr[k];
+                    for (int k = 0; k < nh; k++) { ref[k] = cr[k]; dsel[k] = u2f(f2u(ct[k]) & 0xFFF00000u); }
                 }
             } else {
                 const float *nd = s->nodes + 16 * (size_t)cur;
@@ -1481,8 +1490,12 @@ static void traverse(const orc_scene *s, const float o[3], const float d[3], flo
                 else if (h0) { ref[0] = r0; nh = 1; }
                 else if (h1) { ref[0] = r1; nh = 1; }
             }
-            if (nh == 0) { if (sp == 0) break; cur = stack[--sp]; continue; }
-            for (int k = nh - 1; k >= 1; k--) stack[sp++] = ref[k];
+            if (nh == 0) {
+                if (recull && sp > 0 && !(stack[sp - 1] & 0x80000000u) && sdist[sp - 1] > best.t) sp--;
+                if (sp == 0) break;
+                cur = stack[--sp]; continue;
+            }
+            for (int k = nh - 1; k >= 1; k--) { sdist[sp] = dsel[k]; stack[sp++] = ref[k]; }
             cur = ref[0];
         }
     }

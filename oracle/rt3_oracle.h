@@ -126,6 +126,7 @@ void orc_accel_set_tree_order(orc_scene *s, uint32_t on);
 void orc_accel_set_dp_costs(orc_scene *s, float c_node, float c_tri);
 /* experiments only (needs tree order / collapse 2): insertion-based re-optimisation of the tree above subtrees of <= k_top triangles */
 void orc_accel_set_top_opt(orc_scene *s, uint32_t k_top, uint32_t passes);
+void orc_accel_set_recull(orc_scene *s, uint32_t on); /* experiments only (default 0): closest-hit walks drop a popped node reference that lies beyond the current hit */
 /* SAH top: the tree above Karras subtrees of at most cluster_size triangles is re-linked by binned SAH (0 = plain LBVH; default 2) */
 void orc_accel_set_sah_top(orc_scene *s, uint32_t cluster_size);
 uint32_t orc_accel_node_words(const orc_scene *s);

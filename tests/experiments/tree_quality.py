@@ -28,6 +28,7 @@ if __name__ == '__main__':
     mesh = scenes.atrium(1.0); sky = scenes.sky(512, 256); bn = assets.load_bluenoise()
     variants = [
         ('default (T=1 DP)', dict()),
+        ('recull (12-bit distances)', dict(recull=1)),
         ('top-opt k=64 p=2', dict(top_opt=(64, 2))),
         ('top-opt k=256 p=2', dict(top_opt=(256, 2))),
         ('top-opt k=16 p=3', dict(top_opt=(16, 3))),

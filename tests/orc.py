@@ -51,6 +51,7 @@ def lib():
         L.orc_accel_set_tree_order.argtypes = [vp, u32]
         L.orc_accel_set_dp_costs.argtypes = [vp, f32, f32]
         L.orc_accel_set_top_opt.argtypes = [vp, u32, u32]
+        L.orc_accel_set_recull.argtypes = [vp, u32]
         L.orc_scene_set_instances.argtypes = [vp, vp, u32]
         L.orc_scene_set_instances.restype = C.c_int
         L.orc_octa_encode16.argtypes = [vp]
@@ -107,7 +108,7 @@ INSTANCE_DTYPE = np.dtype([("geometry_first", np.uint32), ("geometry_count", np.
 
 
 class Scene:
-    def __init__(self, mesh, sky=None, bluenoise=None, build=True, leaf_size=2, node_width=4, quantized=1, collapse=2, sah_top=1, tree_order=0, instances=None, dp_costs=None, top_opt=None):
+    def __init__(self, mesh, sky=None, bluenoise=None, build=True, leaf_size=2, node_width=4, quantized=1, collapse=2, sah_top=1, tree_order=0, instances=None, dp_costs=None, top_opt=None, recull=0):
         L = lib()
         self.h = L.orc_scene_create()
         L.orc_accel_set_layout(self.h, leaf_size, node_width, quantized)
@@ -118,6 +119,7 @@ class Scene:
             L.orc_accel_set_dp_costs(self.h, *dp_costs)
         if top_opt:
             L.orc_accel_set_top_opt(self.h, *top_opt)
+        L.orc_accel_set_recull(self.h, recull)
         self.mesh = mesh
         v = np.ascontiguousarray(mesh.vertices, np.float32); i = np.ascontiguousarray(mesh.indices, np.uint32)
         L.orc_scene_set_vertices(self.h, ptr(v), len(v))
