@@ -13,7 +13,8 @@ for detail in (1.0, 1.9):
     mesh = scenes.atrium(detail)
     ctx = Context(0)
     ctx.upload_mesh(mesh)
-    for T, dev in ((0, 1), (2, 1), (2, 0), (8, 1)):
+    for collapse, T, dev in ((2, 1, 1), (2, 2, 1), (2, 4, 1), (2, 0, 1), (1, 2, 1), (1, 2, 0), (1, 8, 1)):  # collapse 2 = cost-driven (default, T = 1)
+        ctx.set_option(L.OPT_WIDE_COLLAPSE, collapse)
         ctx.set_option(L.OPT_SAH_TOP, T)
         ctx.set_option(L.OPT_SAH_TOP_DEVICE, dev)
         ts = []
@@ -21,5 +22,5 @@ for detail in (1.0, 1.9):
             t0 = time.perf_counter()
             ctx.build_accel()
             ts.append(1e3 * (time.perf_counter() - t0))
-        print(f"atrium({detail}): {mesh.n_triangles} triangles, SAH_TOP {T} on the {'GPU' if dev else 'host'}: build {min(ts[1:]):.1f} ms (first {ts[0]:.1f})", flush=True)
+        print(f"atrium({detail}): {mesh.n_triangles} triangles, collapse {collapse}, SAH_TOP {T} on the {'GPU' if dev else 'host'}: build {min(ts[1:]):.1f} ms (first {ts[0]:.1f}), {ctx.accel_info()[0]} nodes", flush=True)
     ctx.close()
